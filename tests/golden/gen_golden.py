@@ -1,0 +1,424 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by running the REFERENCE itself.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/gen_golden.py
+
+The reference publishes no tests or golden vectors, so parity is pinned by
+importing its modules here (with inert placeholders for the third-party packages that are not
+installed, see ref_shim.py), feeding them seeded synthetic weights / rays / images, and
+recording inputs + outputs as data.  No reference source is copied; the fixtures are arrays.
+
+Inputs that come from a seeded generator in tgtc_style_amd.synth are stored as seeds/arguments,
+not arrays, to keep the fixtures small; tests regenerate them bit-identically.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_shim  # noqa: E402
+
+_saved = ref_shim.install()
+import dataset as ref_dataset  # noqa: E402
+import function as ref_function  # noqa: E402
+import models as ref_models  # noqa: E402
+import rendering as ref_rendering  # noqa: E402
+import Style_function as ref_style_function  # noqa: E402
+import tctrans as ref_tctrans  # noqa: E402
+import transformer as ref_transformer  # noqa: E402
+import utils as ref_utils  # noqa: E402
+
+ref_shim.restore_env(_saved)
+
+from tgtc_style_amd import synth  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+class Args:
+    """The argparse fields the reference constructors read (config.py defaults + configs/fern.txt)."""
+    use_viewdir = True
+    act_type = "relu"
+    embed_freq_coor = 10
+    embed_freq_dir = 4
+    netdepth = 8
+    netwidth = 256
+    netdepth_fine = 8
+    netwidth_fine = 256
+    style_D = 8
+    vae_latent = 32
+    siren_sigma_mul = 20.0
+    N_samples = 64
+    N_samples_fine = 64
+    dataset_type = "llff"
+
+
+def t(sd):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-22s %8.1f KB  %s" % (name, os.path.getsize(path) / 1024, sorted(out)))
+
+
+def make_nerf(seed, mode, args=Args):
+    m = ref_models.StyleNerf(args, mode=mode).eval()
+    m.load_state_dict(t(synth.nerf_state(seed)))
+    return m
+
+
+def test_rays(n, seed, spread=1.0):
+    """Seeded NDC-like rays: origins on the near plane (oz=-1), d_z = 2 (after the NDC warp)."""
+    rng = np.random.default_rng(seed)
+    o = np.concatenate([rng.uniform(-spread, spread, (n, 2)), -np.ones((n, 1))], 1)
+    d = np.concatenate([rng.uniform(-0.3, 0.3, (n, 2)), 2.0 * np.ones((n, 1))], 1)
+    return o.astype(np.float64), d.astype(np.float64)
+
+
+# ----------------------------------------------------------------------------- G1 rays
+def g1_rays():
+    out = {}
+    for tag, (H, W) in {"a": (12, 16), "b": (16, 16)}.items():
+        focal = synth.fern_intrinsics(H, W)
+        K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+        for pi in (0, 37):
+            c2w = synth.spiral_pose(pi)
+            for pa in (False, True):
+                ro, rd = ref_dataset.get_rays_np(H, W, K, c2w, pa)
+                # dataset.py:420-433 stores into float64 buffers, then warps
+                ro64, rd64 = np.zeros([H, W, 3]), np.zeros([H, W, 3])
+                ro64[:], rd64[:] = ro, rd
+                no, nd = ref_dataset.ndc_rays_np(H, W, K[0][0], 1., ro64, rd64)
+                key = "%s_p%d_%d" % (tag, pi, int(pa))
+                out[key + "_o"], out[key + "_d"] = ro64, rd64
+                out[key + "_ndc_o"], out[key + "_ndc_d"] = no, nd
+    save("g1_rays", **out)
+
+
+# ----------------------------------------------------------------------------- G2 coarse sampling
+def g2_coarse():
+    out = {}
+    ro, rd = test_rays(16, 100)
+    out["rays_o"], out["rays_d"] = ro, rd
+    for n in (64, 128):
+        pts, ts = ref_utils.sampling_pts_uniform(torch.from_numpy(ro), torch.from_numpy(rd), N_samples=n,
+                                                 near=0., far=1., perturb=False)
+        out["pts_%d" % n], out["ts_%d" % n] = pts, ts
+        torch.manual_seed(1234 + n)
+        pts, ts = ref_utils.sampling_pts_uniform(torch.from_numpy(ro), torch.from_numpy(rd), N_samples=n,
+                                                 near=0., far=1., perturb=True)
+        torch.manual_seed(1234 + n)   # the jitter is the function's first RNG draw (utils.py:519-520)
+        jit = torch.zeros([16, n])
+        torch.nn.init.uniform_(jit, 0, 1)
+        out["jit_%d" % n], out["pts_jit_%d" % n], out["ts_jit_%d" % n] = jit, pts, ts
+    save("g2_coarse", **out)
+
+
+# ----------------------------------------------------------------------------- G3 embedder
+def g3_embed():
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1.5, 1.5, (40, 3))
+    x[0] = 0.0
+    x[1] = 1.0
+    x[2] = -1.0
+    x[3] = [1.5, -1.5, 0.5]
+    x = torch.from_numpy(x)
+    e10 = ref_models.Embedder(input_dim=3, max_freq_log2=9, N_freqs=10)
+    e4 = ref_models.Embedder(input_dim=3, max_freq_log2=3, N_freqs=4)
+    save("g3_embed", x=x, pe10_f64=e10(x), pe4_f64=e4(x), pe10_f32in=e10(x.float()), pe4_f32in=e4(x.float()))
+
+
+# ----------------------------------------------------------------------------- G4 NeRF MLP
+def g4_nerf():
+    out = {}
+    ro, rd = test_rays(4, 400)
+    ro_t, rd_t = torch.from_numpy(ro), torch.from_numpy(rd)
+    rng = np.random.default_rng(401)
+    ts = np.sort(rng.uniform(0, 1, (4, 192)).astype(np.float32), -1)
+    pts = ro_t[:, None, :] + torch.from_numpy(ts)[..., None] * rd_t[:, None, :]
+    dirs = rd_t[:, None, :].expand(-1, 192, -1)
+    out["rays_o"], out["rays_d"], out["ts"] = ro, rd, ts
+    for name, seed, mode in (("coarse", 0, "coarse"), ("fine", 1, "fine")):
+        m = make_nerf(seed, mode)
+        with torch.no_grad():
+            ret = m(pts=pts, dirs=dirs)
+        out[name + "_rgb"], out[name + "_sigma"] = ret["rgb"], ret["sigma"]
+        out[name + "_remap_first48"] = ret["base_remap"][:, :48]
+        out[name + "_pts_enc_first8"] = ret["pts"][:, :8]
+        out[name + "_dirs_enc_first8"] = ret["dirs"][:, :8]
+        # the granular MLP_style.forward on already-encoded float32 inputs (models.py:95)
+        with torch.no_grad():
+            ret2 = m.net(pts=ret["pts"], dirs=ret["dirs"])
+        out[name + "_mlp_rgb"], out[name + "_mlp_sigma"] = ret2["rgb"], ret2["sigma"]
+    save("g4_nerf", **out)
+
+
+# ----------------------------------------------------------------------------- G5 compositing
+def g5_composite():
+    rng = np.random.default_rng(5)
+    R, N = 12, 64
+    rgb = rng.uniform(0, 1, (R, N, 3)).astype(np.float32)
+    sigma = (rng.standard_normal((R, N)) * 20).astype(np.float32)
+    ts = np.sort(rng.uniform(0, 1, (R, N)).astype(np.float32), -1)
+    sigma[1] = -np.abs(sigma[1])          # all negative -> zero weights
+    sigma[2] = 0.0                        # all zero
+    sigma[3, 10] = 1e6                    # one huge density
+    ts[4, 20:24] = ts[4, 20]              # repeated depths -> zero deltas
+    sigma[5] = 500.0                      # opaque from the first sample
+    ts[6] = np.linspace(0, 1, N, dtype=np.float32)
+    out = {"rgb": rgb, "sigma": sigma, "ts": ts}
+    r, te, w = ref_utils.alpha_composition(torch.from_numpy(rgb), torch.from_numpy(sigma), torch.from_numpy(ts), 0)
+    out["rgb_exp"], out["t_exp"], out["weights"] = r, te, w
+    # a 192-sample case (fine pass length)
+    N2 = 192
+    rgb2 = rng.uniform(0, 1, (6, N2, 3)).astype(np.float32)
+    sigma2 = (rng.standard_normal((6, N2)) * 40).astype(np.float32)
+    ts2 = np.sort(rng.uniform(0, 1, (6, N2)).astype(np.float32), -1)
+    r, te, w = ref_utils.alpha_composition(torch.from_numpy(rgb2), torch.from_numpy(sigma2), torch.from_numpy(ts2), 0)
+    out.update(rgb2=rgb2, sigma2=sigma2, ts2=ts2, rgb_exp2=r, t_exp2=te, weights2=w)
+    save("g5_composite", **out)
+
+
+# ----------------------------------------------------------------------------- G6 fine sampling
+def g6_fine():
+    rng = np.random.default_rng(6)
+    out = {}
+    for N, NF in ((64, 64), (128, 64)):
+        R = 10
+        ro, rd = test_rays(R, 600 + N)
+        ts = torch.linspace(0, 1, N).expand(R, N).contiguous().numpy().copy()
+        ts[8] = np.sort(rng.uniform(0, 1, N).astype(np.float32))      # jittered depths
+        ts[9] = np.sort(rng.uniform(0, 1, N).astype(np.float32))
+        w = rng.uniform(0, 1, (R, N)).astype(np.float32) ** 4
+        w[1] = 0.0                                   # all zero -> uniform pdf
+        w[2] = 0.0; w[2, 1] = 1.0                    # spike in the first interior bin
+        w[3] = 0.0; w[3, N - 2] = 1.0                # spike in the last interior bin
+        w[4] = 0.0; w[4, N // 2] = 5.0               # single spike: long flat cdf stretches (denom<1e-5 path)
+        w[5] = 0.0; w[5, 0] = 1.0; w[5, N - 1] = 1.0  # only the dropped end weights are non-zero
+        w[6] = 1.0                                   # exactly uniform
+        w[7] = 0.0; w[7, 10] = 0.5; w[7, 11] = 0.5
+        pts, tv = ref_utils.sampling_pts_fine_torch(torch.from_numpy(ro), torch.from_numpy(rd),
+                                                    torch.from_numpy(ts), torch.from_numpy(w), NF)
+        mid = 0.5 * (torch.from_numpy(ts)[..., 1:] + torch.from_numpy(ts)[..., :-1])
+        smp = ref_utils.sample_pdf(mid, torch.from_numpy(w)[..., 1:-1], NF, det=True)
+        tag = "_%d" % N
+        out.update({"rays_o" + tag: ro, "rays_d" + tag: rd, "ts" + tag: ts, "w" + tag: w,
+                    "pts" + tag: pts, "tvals" + tag: tv, "samples" + tag: smp})
+    save("g6_fine", **out)
+
+
+# ----------------------------------------------------------------------------- G7 latents + style MLPs
+def g7_style():
+    out = {}
+    lat = ref_models.StyleLatents_variational(style_num=2, frame_num=20, latent_dim=32)
+    lat.load_state_dict(t(synth.latents_state(4, style_num=2, frame_num=20)))
+    sid = torch.tensor([0, 0, 1, 1, 0, 1, 0, 1], dtype=torch.long)
+    fid = torch.tensor([0, 19, 3, 19, 25, 40, 119, 119], dtype=torch.long)   # ids >= frame_num wrap via repeat(7)
+    out["style_ids"], out["frame_ids"] = sid, fid
+    for sc in (0.0, 1.0, 0.35):
+        lat.sigma_scale = sc
+        with torch.no_grad():
+            out["latents_s%g" % sc] = lat(style_ids=sid, frame_ids=fid, type="llff")
+
+    rng = np.random.default_rng(7)
+    M = 24
+    x = rng.uniform(-1, 1, (M, 63)).astype(np.float32)
+    z = rng.standard_normal((M, 32)).astype(np.float32)
+    conc = np.maximum(rng.standard_normal((M, 512)), 0).astype(np.float32)
+    cm = ref_models.StyleMLP_before_concat(Args).eval()
+    cm.load_state_dict(t(synth.concat_state(2)))
+    sm = ref_models.StyleMLP_Wild_multilayers(Args).eval()
+    sm.load_state_dict(t(synth.style_state(3)))
+    with torch.no_grad():
+        cf = cm(x=torch.from_numpy(x), latent=torch.from_numpy(z))["concat_features"]
+        rgb = sm(x=torch.from_numpy(x), concated=torch.from_numpy(conc), latent=torch.from_numpy(z))["rgb"]
+    out.update(x=x, z=z, conc=conc, concat_features=cf, style_rgb=rgb)
+    save("g7_style", **out)
+
+
+# ----------------------------------------------------------------------------- G8 end-to-end
+class _FakeDataset:
+    """Just the attributes rendering.cal_geometry reads (rendering.py:9-14)."""
+
+    def __init__(self, h, w, near, far, cps):
+        self.mode = "train"
+        self.cps = cps
+        self.cps_valid = cps
+        self.hwf = [h, w, synth.fern_intrinsics(h, w)]
+        self.near, self.far = near, far
+        self.frame_num, self.h, self.w = cps.shape[0], h, w
+
+
+class _FakeLoader:
+    def __init__(self, dataset, batches):
+        self.dataset = dataset
+        self._b = batches
+
+    def __iter__(self):
+        return iter(self._b)
+
+    def __len__(self):
+        return len(self._b)
+
+
+def g8_end_to_end():
+    out = {}
+    for nc, nf in ((128, 64), (64, 64)):
+        tag = "_%dc%df" % (nc, nf)
+        a = type("A", (Args,), {"N_samples": nc, "N_samples_fine": nf})
+        h = w = 8
+        ro, rd = test_rays(h * w, 800 + nc)
+        coarse, fine = make_nerf(0, "coarse", a), make_nerf(1, "fine", a)
+        fwd_c = ref_utils.batchify(lambda **kw: coarse(**kw), 32)
+        fwd_f = ref_utils.batchify(lambda **kw: fine(**kw), 32)
+        ds = _FakeDataset(h, w, 0., 1., np.eye(4, dtype=np.float32)[None])
+        batches = [{"rays_o": torch.from_numpy(ro[i:i + 32]), "rays_d": torch.from_numpy(rd[i:i + 32])}
+                   for i in range(0, h * w, 32)]
+        with tempfile.TemporaryDirectory() as tmp, torch.no_grad():
+            rgb_map, t_map = ref_rendering.cal_geometry(
+                model_forward=fwd_c, samp_func=ref_utils.sampling_pts_uniform, dataloader=_FakeLoader(ds, batches),
+                args=a, device="cpu", sv_path=tmp, model_forward_fine=fwd_f,
+                samp_func_fine=ref_utils.sampling_pts_fine_torch)
+        out.update({"rays_o" + tag: ro, "rays_d" + tag: rd,
+                    "plain_rgb" + tag: rgb_map.reshape(-1, 3), "plain_t" + tag: t_map.reshape(-1)})
+
+        # stylised chain: the reference callables in the order rendering.render_style applies them
+        # (rendering.py:118-178); render_style itself only hands back the unconsumed tail, so the
+        # per-batch results are collected here.
+        coarse.set_enable_style(True)
+        fine.set_enable_style(True)
+        cm = ref_models.StyleMLP_before_concat(a).eval()
+        cm.load_state_dict(t(synth.concat_state(2)))
+        sm = ref_models.StyleMLP_Wild_multilayers(a).eval()
+        sm.load_state_dict(t(synth.style_state(3)))
+        lat = ref_models.StyleLatents_variational(style_num=1, frame_num=20, latent_dim=32)
+        lat.load_state_dict(t(synth.latents_state(4)))
+        lat.sigma_scale = 1.0
+        R = h * w
+        sid = torch.zeros(R, dtype=torch.long)
+        fid = torch.full((R,), 33, dtype=torch.long)
+        ro_t, rd_t = torch.from_numpy(ro), torch.from_numpy(rd)
+        for jit_tag, seed in (("", None), ("_jit", 4321 + nc)):
+            with torch.no_grad():
+                if seed is None:
+                    pts, ts = ref_utils.sampling_pts_uniform(rays_o=ro_t, rays_d=rd_t, N_samples=nc, near=0., far=1., perturb=False)
+                else:
+                    torch.manual_seed(seed)
+                    pts, ts = ref_utils.sampling_pts_uniform(rays_o=ro_t, rays_d=rd_t, N_samples=nc, near=0., far=1., perturb=True)
+                    torch.manual_seed(seed)
+                    jit = torch.zeros([R, nc])
+                    torch.nn.init.uniform_(jit, 0, 1)
+                    out["jit" + tag] = jit
+                z = lat(style_ids=sid, frame_ids=fid, type="llff")
+                zbar = torch.mean(z, dim=1, keepdims=True)
+
+                def one_pass(model, pts, n):
+                    ret = model(pts=pts, dirs=rd_t.unsqueeze(1).expand([R, n, 3]))
+                    z1 = z.unsqueeze(1).expand([R, n, 32])
+                    cf = cm(x=ret["pts"], latent=z1)["concat_features"]
+                    both = torch.concat((ret["base_remap"], cf), dim=-1)
+                    zb = torch.unsqueeze(zbar, dim=2).expand([R, n, 32])
+                    return sm(x=ret["pts"], concated=both, latent=zb)["rgb"], ret["sigma"]
+
+                rgb_s, sig = one_pass(coarse, pts, nc)
+                rc, tc, wc = ref_utils.alpha_composition(rgb_s, sig, ts, 0)
+                pts_f, ts_f = ref_utils.sampling_pts_fine_torch(ro_t, rd_t, ts, wc, nf)
+                rgb_s, sig = one_pass(fine, pts_f, nc + nf)
+                rf, tf, _ = ref_utils.alpha_composition(rgb_s, sig, ts_f, 0)
+            out.update({"styled_rgb_coarse" + jit_tag + tag: rc, "styled_rgb" + jit_tag + tag: rf,
+                        "styled_t" + jit_tag + tag: tf, "styled_ts_fine" + jit_tag + tag: ts_f})
+    save("g8_end_to_end", **out)
+
+
+# ----------------------------------------------------------------------------- G9 2-D style pass
+def g9_style2d():
+    out = {}
+    rng = np.random.default_rng(9)
+    tsd = t(synth.transformer_state(5))
+    tr = ref_transformer.Transformer().eval()
+    tr.load_state_dict(tsd)
+
+    # nn.MultiheadAttention semantics (the module the reference layers wrap, transformer.py:158)
+    q = torch.from_numpy(rng.standard_normal((48, 1, 512)).astype(np.float32))
+    k = torch.from_numpy(rng.standard_normal((30, 1, 512)).astype(np.float32))
+    v = torch.from_numpy(rng.standard_normal((30, 1, 512)).astype(np.float32))
+    with torch.no_grad():
+        o = tr.decoder.layers[0].multihead_attn(q, k, v)[0]
+    out.update(mha_q=q[:, 0], mha_k=k[:, 0], mha_v=v[:, 0], mha_out=o[:, 0])
+
+    src = torch.from_numpy(rng.standard_normal((48, 1, 512)).astype(np.float32))
+    mem = torch.from_numpy(rng.standard_normal((30, 1, 512)).astype(np.float32))
+    with torch.no_grad():
+        es = tr.encoder_s.layers[1](src, pos=None)
+        ec = tr.encoder_c.layers[2](src, pos=src)
+        dl = tr.decoder.layers[1](src, mem, pos=None, query_pos=src * 0.5)
+    out.update(layer_src=src[:, 0], layer_mem=mem[:, 0], enc_s_out=es[:, 0], enc_c_out=ec[:, 0], declayer_out=dl[:, 0])
+
+    # full Transformer.forward on 6x8 content tokens / 5x7 style tokens (shape bug guard: the output
+    # is reshaped with the STYLE map size, so content and style grids must have equal token counts)
+    style_map = torch.from_numpy(rng.standard_normal((1, 512, 6, 8)).astype(np.float32))
+    content_map = torch.from_numpy(rng.standard_normal((1, 512, 6, 8)).astype(np.float32))
+    with torch.no_grad():
+        hs = tr(style_map, None, content_map, content_map, None)
+    out.update(tr_style=style_map, tr_content=content_map, tr_hs=hs)
+
+    # patch embed, CNN decoder, VGG
+    pe = ref_tctrans.PatchEmbed().eval()
+    pe.load_state_dict(t(synth.embed_state(6)))
+    dec = ref_tctrans.decoder
+    dec.load_state_dict(t(synth.decoder_state(7)))
+    dec.eval()
+    vgg = torch.nn.Sequential(*list(ref_tctrans.vgg.children())[:31])
+    vgg.load_state_dict(t(synth.vgg_state(8)))
+    vgg.eval()
+    img = torch.from_numpy(rng.uniform(0, 1, (1, 3, 21, 29)).astype(np.float32))   # odd -> floor in embed, ceil in pools
+    with torch.no_grad():
+        emb = pe(img)
+        d_in = torch.from_numpy(rng.standard_normal((1, 512, 3, 4)).astype(np.float32))
+        d_out = dec(d_in)
+    out.update(img=img, embed_out=emb, cnn_in=d_in, cnn_out=d_out)
+
+    net = ref_tctrans.StyTrans(vgg, dec, pe, tr).eval()
+    with torch.no_grad():
+        feats = net.encode_with_intermediate(img)
+    assert torch.equal(feats[3], feats[4])     # enc_5 is empty for vgg[:31] -> identity (tctrans.py:146)
+    for i, f in enumerate(feats[:4]):
+        out["vgg_%d" % (i + 1)] = f
+    m, s = ref_function.calc_mean_std(feats[2])
+    m2, s2 = ref_style_function.calc_mean_std(feats[2])
+    assert torch.equal(m, m2) and torch.equal(s, s2)
+    out.update(ms_mean=m, ms_std=s)
+    out["adain"] = ref_style_function.adaptive_instance_normalization(feats[1], feats[1].flip(-1) * 0.5 + 0.1)
+
+    # StyTrans test branch (H != W selects it, tctrans.py:187,233-245) + trans_test post-processing
+    content = torch.from_numpy(rng.uniform(0, 1, (1, 3, 40, 56)).astype(np.float32))
+    style = torch.from_numpy(synth.style_image(11, 40, 56))
+    with torch.no_grad():
+        ics, hs2 = net(content, style)
+        up = torch.nn.Upsample(size=(40, 56), mode="bilinear", align_corners=True)(ics)   # trans_test.py:172-173
+        rows = hs2.reshape(-1, 512)                                                        # trans_test.py:176
+        feat = torch.cat([rows.mean(dim=0), rows.var(dim=0)])[None]
+    out.update(st_content=content, st_hs=hs2, st_ics=ics, st_image=up, st_feature=feat)
+    save("g9_style2d", **out)
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for fn in (g1_rays, g2_coarse, g3_embed, g4_nerf, g5_composite, g6_fine, g7_style, g8_end_to_end, g9_style2d):
+        if not only or fn.__name__.split("_")[0] in only:
+            fn()

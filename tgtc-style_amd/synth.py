@@ -1,0 +1,203 @@
+"""Seeded synthetic weights, poses and frames (no dataset or checkpoint is available offline).
+
+Framework independent (numpy PCG64), so golden generation, the oracle, the HIP path and
+bench.py all see bit-identical parameters.  State-dict key names and shapes are the
+reference's (models.py:63-94, :120-163, :475-486; transformer.py:13-44;
+tctrans.py:13-99) so the dicts load straight into the reference modules.
+
+Seeds follow SURVEY.md section 8d: 0 coarse NeRF, 1 fine NeRF, 2 concat MLP, 3 style MLP, 4 latents,
+5 ViT (Xavier-uniform on matrices, transformer.py:41-44), 6 patch-embed / CNN decoder / VGG.
+"""
+import math
+
+import numpy as np
+
+PE_COOR = 63   # 3 + 3*2*10  (models.py:190-191)
+PE_DIR = 27    # 3 + 3*2*4   (models.py:192-193)
+LATENT = 32    # config.py:86
+HIDDEN_GAIN = math.sqrt(6.0)   # He-uniform: nn.Linear's default bound 1/sqrt(fan_in) x sqrt(6) keeps ReLU activations O(1)
+SIGMA_GAIN = 500.0             # sigma head scaled up (std ~100) so densities are peaky and the fine sampler is exercised
+SIGMA_SHIFT = -40.0            # ... and centred below zero so most samples are empty space (first hit varies per ray)
+
+
+def _linear(rng, out_f, in_f, gain=1.0):
+    b = 1.0 / math.sqrt(in_f)
+    w = rng.uniform(-b, b, size=(out_f, in_f)).astype(np.float32) * np.float32(gain)
+    bias = rng.uniform(-b, b, size=(out_f,)).astype(np.float32) * np.float32(gain)
+    return w, bias
+
+
+def nerf_state(seed, depth=8, width=256, skips=(4,), use_viewdir=True, sigma_gain=SIGMA_GAIN,
+               sigma_shift=SIGMA_SHIFT, gain=HIDDEN_GAIN):
+    """StyleNerf state dict (keys `net.*`).  Shapes: models.py:76-93."""
+    rng = np.random.default_rng(seed)
+    sd, dim = {}, PE_COOR
+    for i in range(depth):
+        sd["net.base_layers.%d.weight" % i], sd["net.base_layers.%d.bias" % i] = _linear(rng, width, dim, gain)
+        dim = width
+        if i in skips and i != depth - 1:
+            dim += PE_COOR
+    w, b = _linear(rng, 1, dim, sigma_gain)
+    # zero-mean sigma weights decouple the density level from the (positive) mean activation, so
+    # sigma ~ N(sigma_shift, (0.2*sigma_gain)^2) for every seed
+    sd["net.sigma_layer.weight"] = (w - w.mean()).astype(np.float32)
+    sd["net.sigma_layer.bias"] = (b * np.float32(0) + np.float32(sigma_shift)).astype(np.float32)
+    sd["net.base_remap_layer.weight"], sd["net.base_remap_layer.bias"] = _linear(rng, 256, dim, gain)
+    d = 256 + PE_DIR if use_viewdir else 256
+    sd["net.rgb_layers.0.weight"], sd["net.rgb_layers.0.bias"] = _linear(rng, width // 2, d, gain)
+    sd["net.rgb_layers.1.weight"], sd["net.rgb_layers.1.bias"] = _linear(rng, 3, width // 2, gain)
+    return sd
+
+
+def concat_state(seed=2, style_D=8, width=256, skip=4, gain=HIDDEN_GAIN):
+    """StyleMLP_before_concat state dict (keys `layers.*`).  models.py:121-135: the loop breaks
+    after appending the skip layer, so there are skip+1 layers."""
+    rng = np.random.default_rng(seed)
+    sd, dim = {}, PE_COOR + LATENT
+    for i in range(style_D - 1):
+        if i == skip:
+            dim += PE_COOR
+        sd["layers.%d.weight" % i], sd["layers.%d.bias" % i] = _linear(rng, width, dim, gain)
+        if i == skip:
+            break
+        dim = width + LATENT
+    return sd
+
+
+def style_state(seed=3, style_D=8, width=256, skip=4, gain=HIDDEN_GAIN):
+    """StyleMLP_Wild_multilayers state dict.  models.py:150-163."""
+    rng = np.random.default_rng(seed)
+    sd, dim = {}, PE_COOR + 512 + LATENT
+    for i in range(style_D - 1):
+        if i == skip:
+            dim += PE_COOR
+        sd["layers.%d.weight" % i], sd["layers.%d.bias" % i] = _linear(rng, width, dim, gain)
+        dim = width + LATENT
+    sd["layers.%d.weight" % (style_D - 1)], sd["layers.%d.bias" % (style_D - 1)] = _linear(rng, 3, width + LATENT, gain)
+    return sd
+
+
+def latents_state(seed=4, style_num=1, frame_num=20, dim=LATENT):
+    """StyleLatents_variational parameters ~ N(0,1).  models.py:482-486."""
+    rng = np.random.default_rng(seed)
+    return {"latents": rng.standard_normal((style_num, frame_num, dim)).astype(np.float32),
+            "style_latents_mu": rng.standard_normal((style_num, dim)).astype(np.float32),
+            "style_latents_logvar": rng.standard_normal((style_num, dim)).astype(np.float32)}
+
+
+def _xavier(rng, *shape):
+    fan_out, fan_in = shape[0], int(np.prod(shape[1:]))
+    a = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-a, a, size=shape).astype(np.float32)
+
+
+def transformer_state(seed=5, d=512, ff=2048, n_enc=3, n_dec=3):
+    """Transformer state dict, 142 keys.  Matrices Xavier-uniform
+    (transformer.py:41-44); biases small uniform (not zero, so bias handling is exercised);
+    LayerNorm weight ~ 1 +- 0.1."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def small(n):
+        return rng.uniform(-0.05, 0.05, size=(n,)).astype(np.float32)
+
+    def norm(p):
+        sd[p + ".weight"] = (1.0 + rng.uniform(-0.1, 0.1, size=(d,))).astype(np.float32)
+        sd[p + ".bias"] = small(d)
+
+    def attn(p):
+        sd[p + "in_proj_weight"] = _xavier(rng, 3 * d, d)
+        sd[p + "in_proj_bias"] = small(3 * d)
+        sd[p + "out_proj.weight"] = _xavier(rng, d, d)
+        sd[p + "out_proj.bias"] = small(d)
+
+    def ffn(p):
+        sd[p + "linear1.weight"] = _xavier(rng, ff, d)
+        sd[p + "linear1.bias"] = small(ff)
+        sd[p + "linear2.weight"] = _xavier(rng, d, ff)
+        sd[p + "linear2.bias"] = small(d)
+
+    for enc in ("encoder_c", "encoder_s"):
+        for i in range(n_enc):
+            p = "%s.layers.%d." % (enc, i)
+            sd[p + "qk.weight"] = _xavier(rng, 2 * d, d)
+            sd[p + "qkv.weight"] = _xavier(rng, 3 * d, d)
+            attn(p + "self_attn.")
+            ffn(p)
+            norm(p + "norm1")
+            norm(p + "norm2")
+    for i in range(n_dec):
+        p = "decoder.layers.%d." % i
+        attn(p + "self_attn.")
+        attn(p + "multihead_attn.")
+        ffn(p)
+        norm(p + "norm1")
+        norm(p + "norm2")
+        norm(p + "norm3")
+    norm("decoder.norm")
+    sd["new_ps.weight"] = _xavier(rng, d, d, 1, 1)
+    sd["new_ps.bias"] = small(d)
+    return sd
+
+
+def _conv(rng, out_c, in_c, k):
+    b = 1.0 / math.sqrt(in_c * k * k)
+    return (rng.uniform(-b, b, size=(out_c, in_c, k, k)).astype(np.float32),
+            rng.uniform(-b, b, size=(out_c,)).astype(np.float32))
+
+
+# Sequential index -> (out_ch, in_ch) for the 3x3 convs of the CNN decoder (tctrans.py:36-66)
+DECODER_SHAPES = {1: (256, 512), 5: (256, 256), 8: (256, 256), 11: (256, 256), 14: (128, 256),
+                  18: (128, 128), 21: (64, 128), 25: (64, 64), 28: (3, 64)}
+# Sequential index -> (out_ch, in_ch, k) for vgg[:31] (tctrans.py:68-99)
+VGG_SHAPES = {0: (3, 3, 1), 2: (64, 3, 3), 5: (64, 64, 3), 9: (128, 64, 3), 12: (128, 128, 3),
+              16: (256, 128, 3), 19: (256, 256, 3), 22: (256, 256, 3), 25: (256, 256, 3), 29: (512, 256, 3)}
+
+
+def embed_state(seed=6):
+    rng = np.random.default_rng(seed)
+    w, b = _conv(rng, 512, 3, 8)
+    return {"proj.weight": w, "proj.bias": b}
+
+
+def decoder_state(seed=7, gain=1.6):
+    """CNN decoder convs; default-init weights shrink activations ~x0.58 per ReLU conv, so a gain
+    keeps the 9-conv chain O(1) (otherwise outputs collapse to the biases and test nothing)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for idx, (o, i) in DECODER_SHAPES.items():
+        w, b = _conv(rng, o, i, 3)
+        sd["%d.weight" % idx], sd["%d.bias" % idx] = w * np.float32(gain), b
+    return sd
+
+
+def vgg_state(seed=8, gain=1.6):
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for idx, (o, i, k) in VGG_SHAPES.items():
+        w, b = _conv(rng, o, i, k)
+        sd["%d.weight" % idx], sd["%d.bias" % idx] = w * np.float32(gain if k == 3 else 1.0), b
+    return sd
+
+
+def spiral_pose(i, n=120, radius=0.25):
+    """A small seeded camera motion about identity: 3x4 float32 c2w, looking down -z, in the spirit of
+    load_llff.render_path_spiral (load_llff.py:145-154) but closed-form and data-free."""
+    a = 2.0 * math.pi * i / n
+    eye = np.array([radius * math.cos(a), -radius * math.sin(a), -0.3 * radius * math.sin(0.5 * a)])
+    target = np.array([0.0, 0.0, -4.0])
+    z = eye - target
+    z /= np.linalg.norm(z)
+    x = np.cross(np.array([0.0, 1.0, 0.0]), z)
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    return np.concatenate([np.stack([x, y, z], 1), eye[:, None]], 1).astype(np.float32)
+
+
+def fern_intrinsics(H, W):
+    """fern-like focal: focal = 0.82*W."""
+    return 0.82 * W
+
+
+def style_image(seed, H, W):
+    return np.random.default_rng(seed).uniform(0, 1, size=(1, 3, H, W)).astype(np.float32)
