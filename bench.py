@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/sec of the plain NeRF render (128 coarse + 64 fine samples per ray) on
+synthetic fern-shaped 400x400 frames, one process per GPU.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = every rank renders ONE whole 400x400 frame (160 000 rays) of its own camera pose:
+on-device ray generation (+NDC warp) -> coarse sampling -> fused PE+NeRF MLP (sigma) -> compositing ->
+inverse-CDF fine sampling -> fused PE+NeRF MLP (rgb, sigma) -> compositing, then (N > 1) one RCCL
+all-gather of the [160000, 4] RGB+depth images so that every rank holds all N frames.  Per-GPU work is
+fixed as N grows (weak scaling); `value` = N * 160000 * steps / max-over-ranks wall time.
+Inputs resident in HBM when the timed region starts: packed weights, camera poses.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (fused NeRF MLP kernel, fine pass, measured
+live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle on the host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 400
+N_COARSE, N_FINE = 128, 64
+MAC_FULL = 593408          # MACs per sample, full NeRF
+MAC_SIGMA = 491264         # MACs per sample, trunk + sigma head
+FLOP_PER_RAY = 2 * (N_COARSE * MAC_SIGMA + (N_COARSE + N_FINE) * MAC_FULL)   # 353.6 MFLOP
+PEAK_FP16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
+
+
+class NetArgs:
+    use_viewdir, act_type = True, "relu"
+    embed_freq_coor, embed_freq_dir = 10, 4
+    netdepth = netdepth_fine = 8
+    netwidth = netwidth_fine = 256
+    precision = "fp16x3"
+
+
+def t_state(sd):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+
+def build_nets(precision):
+    from tgtc_style_amd import models, synth
+    nets = []
+    for seed, mode in ((0, "coarse"), (1, "fine")):
+        a = type("A", (NetArgs,), {"precision": precision})
+        m = models.StyleNerf(a, mode=mode)
+        m.load_state_dict(t_state(synth.nerf_state(seed)))
+        m = m.cuda()
+        m.packed()
+        nets.append(m)
+    return nets
+
+
+def cpu_baseline(n_rays, chunk=1024):
+    """The CPU oracle (plain PyTorch restatement of the reference, pinned to the reference's goldens) on a
+    bounded sample of the same workload; same chunking as the reference CLI (--chunk 1024)."""
+    from oracle import fields, rays
+    from tgtc_style_amd import synth
+    # a one-GPU box gives this job a 16-CPU share; more torch threads than that only thrash
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(cores)
+    c, f = t_state(synth.nerf_state(0)), t_state(synth.nerf_state(1))
+    o, d = rays.frame_rays_ndc(H, W, synth.fern_intrinsics(H, W), synth.spiral_pose(0))
+    o, d = torch.from_numpy(o[:n_rays + chunk]), torch.from_numpy(d[:n_rays + chunk])
+    with torch.no_grad():
+        fields.render_plain(c, f, o[:chunk], d[:chunk], N_COARSE, N_FINE)       # warm-up chunk
+        t0 = time.perf_counter()
+        for lo in range(chunk, chunk + n_rays, chunk):
+            fields.render_plain(c, f, o[lo:lo + chunk], d[lo:lo + chunk], N_COARSE, N_FINE)
+        dt = time.perf_counter() - t0
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": "%d rays of the same 400x400 frame in chunks of %d after one warm-up chunk, "
+                      "torch %s CPU fp32, %d threads, %.1f s" % (n_rays, chunk, torch.__version__, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--precision", default="fp16x3", choices=["fp16x3", "fp16"])
+    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the CPU baseline sample (0 disables)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from tgtc_style_amd import hip, rendering, synth, utils
+    lib = hip.load()
+    coarse, fine = build_nets(args.precision)
+    renderer = rendering.RayRenderer(coarse, fine)
+    focal = synth.fern_intrinsics(H, W)
+    n_rays = H * W
+    image = torch.empty(n_rays, 4, device="cuda", dtype=torch.float32)
+    gathered = torch.empty(world * n_rays, 4, device="cuda", dtype=torch.float32) if world > 1 else None
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in ev:   # create the underlying hipEvents before handing their handles to the library
+        a.record(); b.record()
+    torch.cuda.synchronize()
+
+    def step(i, timed_idx=None):
+        pose = synth.spiral_pose((i * world + rank) % 120)
+        o, d = utils.gen_rays(H, W, focal, pose)
+        if timed_idx is not None:
+            hip.check(lib.tgtc_time_next_nerf_launch(1, ev[timed_idx][0].cuda_event, ev[timed_idx][1].cuda_event))
+        out = renderer.render(o, d, N_COARSE, N_FINE, near=0., far=1.)
+        image[:, :3] = out["rgb"]
+        image[:, 3] = out["t"]
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, image)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, timed_idx=i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    assert bool(torch.isfinite(image).all())
+
+    if rank == 0:
+        rays_total = world * n_rays * args.steps
+        flop_launch = 2.0 * MAC_FULL * n_rays * (N_COARSE + N_FINE)      # algorithmic flop of one fine-pass launch
+        achieved = flop_launch / (kernel_ms * 1e-3) / 1e12
+        mfma_per_product = 3 if args.precision == "fp16x3" else 1
+        line = {
+            "metric": "rays/sec (128c+64f samples) on fern 400x400",
+            "value": rays_total / dt,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16 MFMA operands split hi+lo (3 products), f32 accumulate" if args.precision == "fp16x3"
+                     else "f16 MFMA operands, f32 accumulate",
+            "data": "synthetic",
+            "config": {"workload": "fern-shaped 400x400 frame, plain NeRF render (style off), 128 coarse + 64 fine "
+                                   "samples/ray, one whole frame per rank per step, seeded random-init weights",
+                       "rays_per_step": world * n_rays, "precision": args.precision, "sharding": "frames",
+                       "algorithmic_mflop_per_ray": FLOP_PER_RAY / 1e6},
+            "roofline": {"bound": "mfma", "kernel": "nerf_mlp_kernel<FULL> (fine pass: PE + 12 dense layers, %d samples)"
+                                                   % (n_rays * (N_COARSE + N_FINE)),
+                         "achieved": achieved, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP16_TFLOPS, "traffic": None,
+                         "kernel_ms": kernel_ms, "algorithmic_tflop_per_launch": flop_launch / 1e12,
+                         "mfma_products_per_algorithmic_product": mfma_per_product,
+                         "mfma_pipe_frac": achieved * mfma_per_product / PEAK_FP16_TFLOPS},
+            "whole_path_tflops": rays_total / dt * FLOP_PER_RAY / 1e12,
+        }
+        if world == 1 and args.cpu_rays > 0:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_rays)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,171 @@
+"""GPU parity of the fused PE + NeRF MLP kernels and the plain render chain, through the C ABI.
+
+Tolerance (BASELINE.json north_star): RGB / sigma within 1e-3 relative of the fp32 reference.
+"relative" is taken against the largest magnitude of the reference tensor (max-norm relative error):
+    err(a, ref) = max|a - ref| / max|ref|
+which is the meaningful reading for sigma (pre-activation values cross zero, where a pointwise
+ratio is unbounded).  Mode fp16x3 (the default, parity mode) must meet 1e-3 everywhere and in fact
+sits near 1e-5; mode fp16 (single fp16 MFMA product) is the documented fast mode and is held to 1e-2.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fields, raymarch
+from tgtc_style_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp16x3": 1e-3, "fp16": 1e-2}
+# what the split-fp16 path actually achieves; guards against silent precision regressions
+TIGHT = {"fp16x3": 5e-5, "fp16": 1e-2}
+
+
+def T(sd, cuda=False):
+    out = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    return {k: v.cuda() for k, v in out.items()} if cuda else out
+
+
+def rel(a, ref):
+    a, ref = torch.as_tensor(a).double().cpu(), torch.as_tensor(np.asarray(ref)).double()
+    return float((a - ref).abs().max() / ref.abs().max())
+
+
+class Args:
+    use_viewdir = True
+    act_type = "relu"
+    embed_freq_coor, embed_freq_dir = 10, 4
+    netdepth = netdepth_fine = 8
+    netwidth = netwidth_fine = 256
+    style_D, vae_latent = 8, 32
+    precision = "fp16x3"
+
+
+def make_nerf(seed, mode, precision):
+    from tgtc_style_amd import models
+    a = type("A", (Args,), {"precision": precision})
+    m = models.StyleNerf(a, mode=mode)
+    m.load_state_dict(T(synth.nerf_state(seed)))
+    return m.cuda()
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16"])
+def test_stylenerf_forward_golden(golden, precision):
+    """StyleNerf.forward (models.py:216-223) on the reference's own outputs (g4)."""
+    g = golden("g4_nerf")
+    ro, rd, ts = (torch.from_numpy(g[k]).cuda() for k in ("rays_o", "rays_d", "ts"))
+    pts = ro[:, None, :] + ts[..., None].double() * rd[:, None, :]
+    dirs = rd[:, None, :].expand(-1, ts.shape[1], -1)
+    for name, seed in (("coarse", 0), ("fine", 1)):
+        m = make_nerf(seed, name, precision)
+        out = m(pts=pts, dirs=dirs)
+        assert list(out.keys()) == ["rgb", "base_remap", "pts", "sigma", "dirs"]
+        assert out["rgb"].shape == (4, 192, 3) and out["sigma"].shape == (4, 192) and out["base_remap"].shape == (4, 192, 256)
+        errs = {"sigma": rel(out["sigma"], g[name + "_sigma"]), "rgb": rel(out["rgb"], g[name + "_rgb"]),
+                "remap": rel(out["base_remap"][:, :48], g[name + "_remap_first48"])}
+        print(precision, name, errs)
+        for k, e in errs.items():
+            assert e <= TOL[precision], (k, e)
+            assert e <= TIGHT[precision], (k, e)
+        # the encodings are exact to float32 rounding in both modes
+        assert rel(out["pts"][:, :8], g[name + "_pts_enc_first8"]) <= 2e-7
+        assert rel(out["dirs"][:, :8], g[name + "_dirs_enc_first8"]) <= 2e-7
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16"])
+def test_mlp_style_forward_encoded_inputs(golden, precision):
+    """MLP_style.forward (models.py:95-117) on already-encoded float32 inputs."""
+    g = golden("g4_nerf")
+    sd = T(synth.nerf_state(0))
+    ro, rd, ts = (torch.from_numpy(g[k]) for k in ("rays_o", "rays_d", "ts"))
+    pts = ro[:, None, :] + ts[..., None].double() * rd[:, None, :]
+    pe = fields.posenc(pts, 10).float()
+    de = fields.posenc(rd[:, None, :].expand(-1, 192, -1), 4).float()
+    m = make_nerf(0, "coarse", precision)
+    out = m.net(pts=pe.cuda(), dirs=de.cuda())
+    assert list(out.keys()) == ["rgb", "base_remap", "pts", "sigma"]
+    assert rel(out["sigma"], g["coarse_mlp_sigma"]) <= TIGHT[precision]
+    assert rel(out["rgb"], g["coarse_mlp_rgb"]) <= TIGHT[precision]
+    ref = fields.nerf_mlp(sd, pe, de)
+    assert rel(out["base_remap"], ref["base_remap"]) <= TIGHT[precision]
+
+
+@pytest.mark.parametrize("M", [1, 15, 16, 17, 255, 256, 257, 1000])
+def test_nerf_ragged_sizes(M):
+    """Tail handling: sample counts around the 16-sample tile and the 128/256-sample workgroup."""
+    rng = np.random.default_rng(M)
+    pts = torch.from_numpy(rng.uniform(-1.2, 1.2, (M, 3)))
+    dirs = torch.from_numpy(rng.uniform(-1, 1, (M, 3)))
+    ref = fields.style_nerf(T(synth.nerf_state(1)), pts, dirs)
+    for precision in ("fp16x3", "fp16"):
+        out = make_nerf(1, "fine", precision)(pts=pts.cuda(), dirs=dirs.cuda())
+        assert out["sigma"].shape == (M,)
+        assert rel(out["sigma"], ref["sigma"]) <= TIGHT[precision] * 2
+        assert rel(out["rgb"], ref["rgb"]) <= TIGHT[precision] * 2
+        assert rel(out["base_remap"], ref["base_remap"]) <= TIGHT[precision] * 2
+
+
+def test_nerf_empty_and_errors():
+    from tgtc_style_amd import hip
+    m = make_nerf(0, "coarse", "fp16x3")
+    out = m(pts=torch.empty(0, 3, dtype=torch.float64).cuda(), dirs=torch.empty(0, 3, dtype=torch.float64).cuda())
+    assert out["sigma"].shape == (0,)
+    # a network the kernels are not built for is refused with an error, not silently mis-evaluated
+    sd = synth.nerf_state(0, width=128)
+    with pytest.raises(RuntimeError, match="built for"):
+        hip.nerf_create({k: torch.from_numpy(v) for k, v in sd.items()}, "fp16x3")
+    with pytest.raises(RuntimeError):
+        m(pts=torch.zeros(4, 3, dtype=torch.float64), dirs=torch.zeros(4, 3, dtype=torch.float64))   # CPU tensors
+
+
+def test_repack_on_weight_change():
+    m = make_nerf(0, "coarse", "fp16x3")
+    pts = torch.from_numpy(np.random.default_rng(0).uniform(-1, 1, (64, 3))).cuda()
+    a = m(pts=pts, dirs=pts)["sigma"].clone()
+    m.load_state_dict({k: v for k, v in T(synth.nerf_state(1)).items()})
+    b = m(pts=pts, dirs=pts)["sigma"]
+    ref = fields.style_nerf(T(synth.nerf_state(1)), pts.cpu(), pts.cpu())["sigma"]
+    assert not torch.allclose(a, b) and rel(b, ref) <= 5e-5
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16"])
+@pytest.mark.parametrize("nc,nf", [(128, 64), (64, 64)])
+def test_render_rays_plain_golden(golden, precision, nc, nf):
+    """The fused cal_geometry chain (rendering.py:27-51) against the reference's own render of 64 rays."""
+    from tgtc_style_amd import rendering
+    g = golden("g8_end_to_end")
+    tag = "_%dc%df" % (nc, nf)
+    ro, rd = torch.from_numpy(g["rays_o" + tag]).cuda(), torch.from_numpy(g["rays_d" + tag]).cuda()
+    r = rendering.RayRenderer(make_nerf(0, "coarse", precision), make_nerf(1, "fine", precision))
+    out = r.render(ro, rd, nc, nf, near=0., far=1., want_coarse=True)
+    # Composited colours live in [0,1] and depths in [0,1]: absolute error == max-norm relative error.
+    # The synthetic density field is deliberately violent (sigma ~ N(-90, 90^2), white-noise along the
+    # ray), so sample positions are ill-conditioned wherever the coarse pdf is flat; see DESIGN.md.
+    e_rgb = float((out["rgb"].cpu() - torch.from_numpy(g["plain_rgb" + tag])).abs().max())
+    e_t = float((out["t"].cpu() - torch.from_numpy(g["plain_t" + tag])).abs().max())
+    print(precision, tag, "rgb", e_rgb, "t", e_t)
+    lim = {"fp16x3": 1e-3, "fp16": 2e-2}[precision]
+    assert e_rgb <= lim and e_t <= lim
+    # same chain assembled from the granular operators (what rendering.cal_geometry does) agrees with the fused call
+    ref = fields.render_plain(T(synth.nerf_state(0)), T(synth.nerf_state(1)), ro.cpu(), rd.cpu(), nc, nf)
+    assert float((out["rgb_coarse"].cpu() - ref["rgb_coarse"]).abs().max()) <= lim
+
+
+def test_render_full_size_properties():
+    """BASELINE size (128c+64f) on a whole 400-wide strip: properties that do not need the oracle."""
+    from tgtc_style_amd import rendering, utils
+    H, W = 400, 400
+    focal = synth.fern_intrinsics(H, W)
+    ro, rd = utils.gen_rays(H, W, focal, synth.spiral_pose(3), first_pixel=0, n=40 * W)
+    r = rendering.RayRenderer(make_nerf(0, "coarse", "fp16x3"), make_nerf(1, "fine", "fp16x3"))
+    a = r.render(ro, rd, 128, 64)
+    assert a["rgb"].shape == (40 * W, 3) and bool(torch.isfinite(a["rgb"]).all())
+    assert float(a["rgb"].min()) >= 0 and float(a["rgb"].max()) <= 1 + 1e-5       # convex combination of sigmoids
+    assert float(a["t"].min()) >= 0 and float(a["t"].max()) <= 1 + 1e-5
+    # rays are independent: any sub-range (a rank's shard, any chunking) reproduces the same bits
+    b = r.render(ro[5000:9000].contiguous(), rd[5000:9000].contiguous(), 128, 64)
+    assert torch.equal(a["rgb"][5000:9000], b["rgb"]) and torch.equal(a["t"][5000:9000], b["t"])
+    # spot check 256 of the rays against the oracle
+    idx = torch.arange(0, 40 * W, 40 * W // 256)[:256]
+    ref = fields.render_plain(T(synth.nerf_state(0)), T(synth.nerf_state(1)), ro[idx].cpu(), rd[idx].cpu(), 128, 64)
+    assert float((a["rgb"][idx].cpu() - ref["rgb_fine"]).abs().max()) <= 1e-3

@@ -1,0 +1,297 @@
+// Building blocks of the fused "positional encoding + MLP" kernels (gfx950 / CDNA4 only).
+//
+// Formulation: every layer is evaluated TRANSPOSED, H_out^T[features x samples] =
+// W[features x K] * H_in^T[K x samples], on v_mfma_f32_16x16x32_f16:
+//   * A operand  = a 16(out-feature) x 32(k) weight fragment, read from an LDS ring that is filled by
+//                  LDS-DMA (global_load_lds_dwordx4) from a pre-packed, fragment-ordered stream in HBM/L2;
+//   * B operand  = activations, which NEVER leave registers: the 16x16 fp32 accumulator tile of layer l
+//                  (feature rows 4*(lane>>4)+r, sample column lane&15) is, after ReLU and conversion to
+//                  fp16, exactly the B fragment layout of layer l+1 for a k-permutation that is folded
+//                  into the weight packing (two 16-row tiles form one 32-deep k-step);
+//   * each wavefront owns NCT column tiles of 16 samples and all output features; the 4 waves of a
+//     workgroup share one weight ring, so the weights cross L2->LDS once per 4*NCT*16 samples.
+// Precision: TGTC_PREC_FP16 = one MFMA per product; TGTC_PREC_FP16X3 = weights and activations split
+// into fp16 hi+lo, three MFMAs (hi*hi + lo*hi + hi*lo) per product, fp32 accumulate: fp32-equivalent.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+namespace tgtc {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+#define TGTC_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define TGTC_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int I>
+using ic = std::integral_constant<int, I>;
+
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(ic<Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Geometry shared by the packer (host) and the kernels (device).
+constexpr int kFragHalves = 64 * 8;       // one MFMA A fragment: 64 lanes x 8 halves = 1 KiB
+constexpr int kChunkBytes = 16384;        // ring granule
+constexpr int kRingSlots = 8;             // 128 KiB ring
+constexpr int kRingBytes = kChunkBytes * kRingSlots;
+constexpr int kPrefetchDepth = kRingSlots - 1;
+
+template <int NWAVES_, int NCT_, bool SPLIT_>
+struct MlpCfg {
+    static constexpr int NWAVES = NWAVES_;
+    static constexpr int NCT = NCT_;                       // 16-sample column tiles per wave
+    static constexpr bool SPLIT = SPLIT_;
+    static constexpr int FRAG_BYTES = SPLIT ? 2048 : 1024;  // hi (+ lo) fragment
+    static constexpr int FPC = kChunkBytes / FRAG_BYTES;    // fragments per chunk
+    static constexpr int GPC = kChunkBytes / (NWAVES * 1024);  // LDS-DMA instructions per wave per chunk
+    static constexpr int SAMPLES_PER_WAVE = NCT * 16;
+    static constexpr int SAMPLES_PER_WG = NWAVES * SAMPLES_PER_WAVE;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Weight ring: NCHUNK chunks of the packed stream flow through kRingSlots LDS slots.
+// Protocol per chunk boundary (acquire<CH>): every wave waits (counted vmcnt) until ITS pieces of
+// chunk CH have landed, then the workgroup barrier makes the whole chunk visible; the barrier also
+// proves every wave is done with chunk CH-1, whose slot is the one chunk CH+DEPTH will overwrite.
+template <class C, int NCHUNK>
+struct WeightRing {
+    const char* src;   // per-lane: stream + wave*GPC*1024 + lane*16
+    char* lds_wave;    // wave-uniform: ring + wave*GPC*1024
+    const char* lds_lane;  // per-lane read base: ring + lane*16
+
+    template <int CH>
+    __device__ __forceinline__ void issue() const {
+        if constexpr (CH < NCHUNK) {
+#pragma unroll
+            for (int j = 0; j < C::GPC; ++j)
+                __builtin_amdgcn_global_load_lds(TGTC_GPTR(src + (size_t)CH * kChunkBytes + j * 1024),
+                                                 TGTC_LPTR(lds_wave + (CH % kRingSlots) * kChunkBytes + j * 1024),
+                                                 16, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void prologue() const {
+        static_for<kPrefetchDepth>([&](auto ch) { issue<ch>(); });
+    }
+    template <int CH>
+    __device__ __forceinline__ void acquire() const {
+        constexpr int last = (CH + kPrefetchDepth - 1 < NCHUNK - 1) ? CH + kPrefetchDepth - 1 : NCHUNK - 1;
+        wait_vmcnt<(last - CH) * C::GPC>();
+        __builtin_amdgcn_s_barrier();
+        issue<CH + kPrefetchDepth>();
+    }
+    template <int FRAG, int PART>
+    __device__ __forceinline__ half8 read() const {
+        constexpr int off = ((FRAG / C::FPC) % kRingSlots) * kChunkBytes + (FRAG % C::FPC) * C::FRAG_BYTES + PART * 1024;
+        return *reinterpret_cast<const half8*>(lds_lane + off);
+    }
+};
+
+__device__ __forceinline__ float4v mfma16(half8 a, half8 b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// One dense layer.  B operands: Bh[KS][NCT] (+ Bl in split mode).  Fragment (rt,ks) is stream
+// fragment FRAG0 + rt*KS + ks.  bias_lane points at (bias table) + 4*(lane>>4) floats in LDS.
+// epi(ic<rt>, acc[NCT]) receives the fp32 tile: rows 16*rt + 4*(lane>>4) + r, column = sample lane&15.
+template <class C, int FRAG0, int KS, int RT, int BIAS0, class RingT, class Epi>
+__device__ __forceinline__ void dense_layer(const RingT& ring, const float* bias_lane, const half8 (&Bh)[KS][C::NCT],
+                                            const half8 (&Bl)[KS][C::NCT], Epi&& epi) {
+    static_for<RT>([&](auto rt_) {
+        constexpr int rt = decltype(rt_)::value;
+        float4v acc[C::NCT];
+        const float4v b = *reinterpret_cast<const float4v*>(bias_lane + BIAS0 + 16 * rt);
+#pragma unroll
+        for (int c = 0; c < C::NCT; ++c) acc[c] = b;
+        static_for<KS>([&](auto ks_) {
+            constexpr int ks = decltype(ks_)::value;
+            constexpr int frag = FRAG0 + rt * KS + ks;
+            if constexpr (frag % C::FPC == 0 && frag != 0) ring.template acquire<frag / C::FPC>();
+            const half8 ah = ring.template read<frag, 0>();
+#pragma unroll
+            for (int c = 0; c < C::NCT; ++c) acc[c] = mfma16(ah, Bh[ks][c], acc[c]);
+            if constexpr (C::SPLIT) {
+                const half8 al = ring.template read<frag, 1>();
+#pragma unroll
+                for (int c = 0; c < C::NCT; ++c) acc[c] = mfma16(al, Bh[ks][c], acc[c]);
+#pragma unroll
+                for (int c = 0; c < C::NCT; ++c) acc[c] = mfma16(ah, Bl[ks][c], acc[c]);
+            }
+        });
+        epi(rt_, acc);
+    });
+}
+
+// ReLU + fp16 (hi/lo) conversion of an accumulator tile into the next layer's B fragments:
+// output row tile rt feeds k-step rt/2, elements (rt&1)*4 + r.
+template <class C, int RT_IDX, int KSN>
+__device__ __forceinline__ void store_act(const float4v (&acc)[C::NCT], half8 (&Yh)[KSN][C::NCT],
+                                          half8 (&Yl)[KSN][C::NCT]) {
+#pragma unroll
+    for (int c = 0; c < C::NCT; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = fmaxf(acc[c][r], 0.0f);
+            const half_t h = (half_t)v;
+            Yh[RT_IDX / 2][c][(RT_IDX & 1) * 4 + r] = h;
+            if constexpr (C::SPLIT) Yl[RT_IDX / 2][c][(RT_IDX & 1) * 4 + r] = (half_t)(v - (float)h);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Positional encoding straight into B fragments.
+//
+// k-slot assignment (mirrored by the packer, see pe63_col / pe27_col): lane group g = lane>>4 owns,
+// per sample, 8 (sin,cos) pairs q = 8g+i (i = 0..7) of the 30 (band,coord) pairs of the 63-wide
+// encoding; pair i lives in k-step i>>2, elements 2*(i&3) (sin) and 2*(i&3)+1 (cos).  Pairs 30 and 31
+// carry the raw coordinates (x,y) and (z,0).
+constexpr double kInv2Pi = 0.15915494309189533576888376337251436;
+
+template <bool ACCURATE>
+__device__ __forceinline__ void sincos_turns(double turns, float& s, float& c) {
+    // sin/cos(2*pi*turns) with the range reduction done in float64 (the reference encodes in float64,
+    // models.py:46-60 on float64 points; an fp32 argument of up to ~770 rad would lose 4-5 digits).
+    if constexpr (ACCURATE) {
+        const double t = turns * 4.0;
+        const double n = rint(t);
+        const float a = (float)(t - n) * 1.57079632679489661923f;  // [-pi/4, pi/4]
+        const float a2 = a * a;
+        const float sp = a + a * a2 * (-1.6666654611e-1f + a2 * (8.3321608736e-3f + a2 * (-1.9515295891e-4f)));
+        const float cp = 1.0f - 0.5f * a2 +
+                         a2 * a2 * (4.166664568298827e-2f + a2 * (-1.388731625493765e-3f + a2 * 2.443315711809948e-5f));
+        const int qd = (int)n & 3;
+        float ss = (qd & 1) ? cp : sp, cc = (qd & 1) ? sp : cp;
+        if (qd == 1) cc = -cc;
+        if (qd == 2) ss = -ss, cc = -cc;
+        if (qd == 3) ss = -ss;
+        s = ss, c = cc;
+    } else {
+        const float f = (float)(turns - rint(turns));  // [-0.5, 0.5] turns; v_sin/v_cos take turns
+        s = __builtin_amdgcn_sinf(f);
+        c = __builtin_amdgcn_cosf(f);
+    }
+}
+
+template <bool SPLIT>
+__device__ __forceinline__ void put_pair(half8& hi, half8& lo, int j0, float s, float c) {
+    const half_t hs = (half_t)s, hc = (half_t)c;
+    hi[j0] = hs, hi[j0 + 1] = hc;
+    if constexpr (SPLIT) lo[j0] = (half_t)(s - (float)hs), lo[j0 + 1] = (half_t)(c - (float)hc);
+}
+
+// logical column (0..62) of pair q, function fn (0 sin, 1 cos) in the reference encoding order
+// [x, sin(2^0 x), cos(2^0 x), ...] (models.py:50-57); -1 = padding.
+__host__ __device__ inline int pe_col(int q, int fn, int n_pairs) {
+    if (q < n_pairs) return 3 + 6 * (q / 3) + 3 * fn + q % 3;
+    if (q == n_pairs) return fn;            // (x, y)
+    if (q == n_pairs + 1) return fn == 0 ? 2 : -1;  // (z, pad)
+    return -1;
+}
+
+// 63-wide point encoding -> 2 k-steps.  enc_out (optional) receives the float32 encoding [63].
+template <bool SPLIT, bool ACCURATE>
+__device__ __forceinline__ void encode_point(const double (&p)[3], int g, half8 (&hi)[2], half8 (&lo)[2],
+                                             float* enc_out) {
+    const double rx = p[0] * kInv2Pi, ry = p[1] * kInv2Pi, rz = p[2] * kInv2Pi;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = 8 * g + i;
+        const int band = q / 3, a = q - 3 * band;
+        const double r = a == 0 ? rx : (a == 1 ? ry : rz);
+        float s, c;
+        sincos_turns<ACCURATE>(ldexp(r, band), s, c);
+        if (i >= 6) {  // only lane group 3 reaches the raw pairs 30, 31
+            if (q == 30) s = (float)p[0], c = (float)p[1];
+            if (q == 31) s = (float)p[2], c = 0.0f;
+        }
+        put_pair<SPLIT>(hi[i >> 2], lo[i >> 2], 2 * (i & 3), s, c);
+        if (enc_out) {
+            const int cs = pe_col(q, 0, 30), cc = pe_col(q, 1, 30);
+            enc_out[cs] = s;
+            if (cc >= 0) enc_out[cc] = c;
+        }
+    }
+}
+
+// 27-wide direction encoding -> 1 k-step: lane group g owns pairs q = 4g+i of the 12 (band,coord)
+// pairs; pairs 12, 13 carry (x,y), (z,0); 14, 15 are padding.
+template <bool SPLIT, bool ACCURATE>
+__device__ __forceinline__ void encode_dir(const double (&d)[3], int g, half8& hi, half8& lo, float* enc_out) {
+    const double rx = d[0] * kInv2Pi, ry = d[1] * kInv2Pi, rz = d[2] * kInv2Pi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = 4 * g + i;
+        const int band = q / 3, a = q - 3 * band;
+        const double r = a == 0 ? rx : (a == 1 ? ry : rz);
+        float s, c;
+        sincos_turns<ACCURATE>(ldexp(r, band), s, c);
+        if (q == 12) s = (float)d[0], c = (float)d[1];
+        if (q == 13) s = (float)d[2], c = 0.0f;
+        if (q >= 14) s = 0.0f, c = 0.0f;
+        put_pair<SPLIT>(hi, lo, 2 * i, s, c);
+        if (enc_out && q < 14) {
+            const int cs = pe_col(q, 0, 12), cc = pe_col(q, 1, 12);
+            enc_out[cs] = s;
+            if (cc >= 0) enc_out[cc] = c;
+        }
+    }
+}
+
+// The same fragments from an already-encoded float32 row (MLP_style.forward boundary).
+template <bool SPLIT>
+__device__ __forceinline__ void load_encoded_point(const float* enc, int g, half8 (&hi)[2], half8 (&lo)[2]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = 8 * g + i;
+        const int cs = pe_col(q, 0, 30), cc = pe_col(q, 1, 30);
+        put_pair<SPLIT>(hi[i >> 2], lo[i >> 2], 2 * (i & 3), enc[cs], cc >= 0 ? enc[cc] : 0.0f);
+    }
+}
+template <bool SPLIT>
+__device__ __forceinline__ void load_encoded_dir(const float* enc, int g, half8& hi, half8& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = 4 * g + i;
+        const int cs = pe_col(q, 0, 12), cc = pe_col(q, 1, 12);
+        put_pair<SPLIT>(hi, lo, 2 * i, cs >= 0 ? enc[cs] : 0.0f, cc >= 0 ? enc[cc] : 0.0f);
+    }
+}
+
+// a 32-wide float vector (the style latent) -> 1 k-step in natural order k = 8g + j
+template <bool SPLIT>
+__device__ __forceinline__ void load_vec32(const float* v, int g, half8& hi, half8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = v[8 * g + j];
+        const half_t h = (half_t)x;
+        hi[j] = h;
+        if constexpr (SPLIT) lo[j] = (half_t)(x - (float)h);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-slot -> logical input column maps used by the packer (host).  `g` = lane>>4, `j` = element.
+// activations produced by a previous layer's accumulator tiles:
+__host__ __device__ inline int act_col(int ks, int g, int j) { return 32 * ks + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)); }
+__host__ __device__ inline int pe63_col(int ks, int g, int j) { return pe_col(8 * g + 4 * ks + (j >> 1), j & 1, 30); }
+__host__ __device__ inline int pe27_col(int g, int j) { return pe_col(4 * g + (j >> 1), j & 1, 12); }
+__host__ __device__ inline int vec32_col(int g, int j) { return 8 * g + j; }
+
+}  // namespace tgtc

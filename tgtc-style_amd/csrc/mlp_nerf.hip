@@ -1,0 +1,364 @@
+// Fused positional encoding + NeRF MLP (reference models.py:63-117 MLP_style inside :182-223 StyleNerf;
+// D=8, W=256, skip at 4, view-dependent colour head).  One launch evaluates rgb / sigma for M samples;
+// the [M,256] activations of the 11 dense layers never leave registers (mlp_core.h).
+#include "mlp_core.h"
+#include "mlp_pack.h"
+
+namespace tgtc {
+
+// Stream order and compile-time fragment / bias bookkeeping (must match nerf_specs() below).
+//   layer      L0  L1  L2  L3  L4  L5  L6  L7  SIG REMAP C0  C1
+//   k-steps     2   8   8   8   8  10   8   8   8    8    9   4
+//   row tiles  16  16  16  16  16  16  16  16   1   16    8   1
+constexpr int kNerfKS[12] = {2, 8, 8, 8, 8, 10, 8, 8, 8, 8, 9, 4};
+constexpr int kNerfRT[12] = {16, 16, 16, 16, 16, 16, 16, 16, 1, 16, 8, 1};
+constexpr int nerf_frag0(int l) {
+    int f = 0;
+    for (int i = 0; i < l; ++i) f += kNerfKS[i] * kNerfRT[i];
+    return f;
+}
+constexpr int nerf_bias0(int l) {
+    int b = 0;
+    for (int i = 0; i < l; ++i) b += 16 * kNerfRT[i];
+    return b;
+}
+struct NerfLayout {
+    static constexpr int frag0(int l) { return nerf_frag0(l); }
+    static constexpr int bias0(int l) { return nerf_bias0(l); }
+    static constexpr int kFragsSigma = nerf_frag0(9);   // trunk + sigma head
+    static constexpr int kFragsFull = nerf_frag0(12);   // 1172
+    static constexpr int kBiasFloats = nerf_bias0(12);  // 2464
+};
+
+constexpr int kNerfBiasBytes = 12288;  // 2464 floats padded to a multiple of 4 KiB (4 waves x 1 KiB LDS-DMA)
+static_assert(NerfLayout::kBiasFloats * 4 <= kNerfBiasBytes, "bias table");
+static_assert(NerfLayout::kFragsFull == 1172, "fragment count");
+
+enum InMode { IN_RAYS = 0, IN_PTS = 1, IN_ENC = 2 };
+
+struct NerfArgs {
+    const char* bias;    // device: padded bias table
+    const char* stream;  // device: weight fragment stream
+    long long M;         // samples
+    int N;               // samples per ray (IN_RAYS)
+    // inputs
+    const double* rays_o;
+    const double* rays_d;
+    const float* ts;
+    const double* pts;
+    const double* dirs;
+    const float* pts_enc;
+    const float* dirs_enc;
+    // outputs (any may be null)
+    float* rgb;
+    float* sigma;
+    float* remap;
+    float* out_pts_enc;
+    float* out_dirs_enc;
+};
+
+template <class C, int IN_MODE, bool FULL>
+__global__ void __launch_bounds__(C::NWAVES * 64, 1) nerf_mlp_kernel(NerfArgs a) {
+    constexpr int NCT = C::NCT;
+    constexpr bool SPLIT = C::SPLIT;
+    constexpr int NFRAG = FULL ? NerfLayout::kFragsFull : NerfLayout::kFragsSigma;
+    constexpr int NCHUNK = (NFRAG + C::FPC - 1) / C::FPC;
+    using L = NerfLayout;
+
+    // ALL LDS in one array (a second __shared__ object makes hipcc drain vmcnt before LDS reads).
+    __shared__ __attribute__((aligned(16))) char smem[kRingBytes + kNerfBiasBytes];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, n = lane & 15;
+    const long long s_wave = (long long)blockIdx.x * C::SAMPLES_PER_WG + wave * C::SAMPLES_PER_WAVE;
+
+    // ---- 1. inputs (ordinary loads first: once LDS-DMA is in flight hipcc drains vmcnt(0) for them)
+    double pos[NCT][3], dir[NCT][3];
+    long long sidx[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        long long s = s_wave + c * 16 + n;
+        sidx[c] = s;
+        if (s >= a.M) s = a.M - 1;  // tail: duplicate the last sample, stores are masked
+        if constexpr (IN_MODE == IN_RAYS) {
+            const long long r = (unsigned)s / (unsigned)a.N;  // M < 2^31 is checked at launch
+            const double t = (double)a.ts[s];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dir[c][k] = a.rays_d[r * 3 + k];
+                pos[c][k] = a.rays_o[r * 3 + k] + t * dir[c][k];  // rendering.py:27 / utils.py:529
+            }
+        } else if constexpr (IN_MODE == IN_PTS) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pos[c][k] = a.pts[s * 3 + k], dir[c][k] = a.dirs[s * 3 + k];
+        }
+        if constexpr (IN_MODE != IN_ENC) {
+            // retire the loads before any LDS-DMA is issued (otherwise their wait drains the whole prefetch)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(pos[c][k]), "+v"(dir[c][k]));
+        }
+    }
+
+    half8 pe_h[2][NCT], pe_l[2][NCT], de_h[1][NCT], de_l[1][NCT];
+    if constexpr (IN_MODE == IN_ENC) {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const long long s = sidx[c] < a.M ? sidx[c] : a.M - 1;
+            half8 h2[2], l2[2];
+            load_encoded_point<SPLIT>(a.pts_enc + s * 63, g, h2, l2);
+            pe_h[0][c] = h2[0], pe_h[1][c] = h2[1], pe_l[0][c] = l2[0], pe_l[1][c] = l2[1];
+            if constexpr (FULL) load_encoded_dir<SPLIT>(a.dirs_enc + s * 27, g, de_h[0][c], de_l[0][c]);
+        }
+    }
+
+    // ---- 2. start the weight stream: bias table, then the first kPrefetchDepth chunks
+    WeightRing<C, NCHUNK> ring;
+    ring.src = a.stream + wave * (C::GPC * 1024) + lane * 16;
+    ring.lds_wave = smem + wave * (C::GPC * 1024);
+    ring.lds_lane = smem + lane * 16;
+#pragma unroll
+    for (int j = 0; j < kNerfBiasBytes / (C::NWAVES * 1024); ++j)
+        __builtin_amdgcn_global_load_lds(TGTC_GPTR(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16),
+                                         TGTC_LPTR(smem + kRingBytes + (j * C::NWAVES + wave) * 1024), 16, 0, 0);
+    ring.prologue();
+
+    // ---- 3. positional encoding into B fragments (overlaps the prefetch latency)
+    if constexpr (IN_MODE != IN_ENC) {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const bool live = sidx[c] < a.M;
+            half8 h2[2], l2[2];
+            encode_point<SPLIT, SPLIT>(pos[c], g, h2, l2,
+                                       (a.out_pts_enc && live) ? a.out_pts_enc + sidx[c] * 63 : nullptr);
+            pe_h[0][c] = h2[0], pe_h[1][c] = h2[1], pe_l[0][c] = l2[0], pe_l[1][c] = l2[1];
+            if constexpr (FULL)
+                encode_dir<SPLIT, SPLIT>(dir[c], g, de_h[0][c], de_l[0][c],
+                                         (a.out_dirs_enc && live) ? a.out_dirs_enc + sidx[c] * 27 : nullptr);
+        }
+    }
+
+    const float* bias_lane = reinterpret_cast<const float*>(smem + kRingBytes) + 4 * g;
+    ring.template acquire<0>();
+
+    // ---- 4. trunk
+    half8 Xh[8][NCT], Xl[8][NCT], Yh[8][NCT], Yl[8][NCT];
+    auto to_Y = [&](auto rt_, float4v (&acc)[NCT]) { store_act<C, decltype(rt_)::value, 8>(acc, Yh, Yl); };
+    auto to_X = [&](auto rt_, float4v (&acc)[NCT]) { store_act<C, decltype(rt_)::value, 8>(acc, Xh, Xl); };
+
+    dense_layer<C, L::frag0(0), 2, 16, L::bias0(0)>(ring, bias_lane, pe_h, pe_l, to_Y);
+    dense_layer<C, L::frag0(1), 8, 16, L::bias0(1)>(ring, bias_lane, Yh, Yl, to_X);
+    dense_layer<C, L::frag0(2), 8, 16, L::bias0(2)>(ring, bias_lane, Xh, Xl, to_Y);
+    dense_layer<C, L::frag0(3), 8, 16, L::bias0(3)>(ring, bias_lane, Yh, Yl, to_X);
+    dense_layer<C, L::frag0(4), 8, 16, L::bias0(4)>(ring, bias_lane, Xh, Xl, to_Y);
+    {
+        // skip layer: reference input is cat(pe, h) (models.py:98-99); k order here is [h | pe]
+        half8 Bh[10][NCT], Bl[10][NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) Bh[k][c] = Yh[k][c], Bl[k][c] = Yl[k][c];
+            Bh[8][c] = pe_h[0][c], Bh[9][c] = pe_h[1][c], Bl[8][c] = pe_l[0][c], Bl[9][c] = pe_l[1][c];
+        }
+        dense_layer<C, L::frag0(5), 10, 16, L::bias0(5)>(ring, bias_lane, Bh, Bl, to_X);
+    }
+    dense_layer<C, L::frag0(6), 8, 16, L::bias0(6)>(ring, bias_lane, Xh, Xl, to_Y);
+    dense_layer<C, L::frag0(7), 8, 16, L::bias0(7)>(ring, bias_lane, Yh, Yl, to_X);
+
+    // ---- 5. sigma head (models.py:103): row 0 of a 16-row tile -> lanes 0..15, register 0
+    dense_layer<C, L::frag0(8), 8, 1, L::bias0(8)>(ring, bias_lane, Xh, Xl, [&](auto, float4v (&acc)[NCT]) {
+        if (g == 0 && a.sigma) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+                if (sidx[c] < a.M) a.sigma[sidx[c]] = acc[c][0];
+        }
+    });
+
+    if constexpr (FULL) {
+        // ---- 6. base_remap (models.py:106) and the colour head (models.py:107-111)
+        dense_layer<C, L::frag0(9), 8, 16, L::bias0(9)>(ring, bias_lane, Xh, Xl, [&](auto rt_, float4v (&acc)[NCT]) {
+            constexpr int rt = decltype(rt_)::value;
+            store_act<C, rt, 8>(acc, Yh, Yl);
+            if (a.remap) {
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    if (sidx[c] < a.M) {
+                        float4v v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[c][r], 0.0f);
+                        *reinterpret_cast<float4v*>(a.remap + sidx[c] * 256 + 16 * rt + 4 * g) = v;
+                    }
+            }
+        });
+        half8 Zh[4][NCT], Zl[4][NCT];
+        {
+            half8 Bh[9][NCT], Bl[9][NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) Bh[k][c] = Yh[k][c], Bl[k][c] = Yl[k][c];
+                Bh[8][c] = de_h[0][c], Bl[8][c] = de_l[0][c];
+            }
+            dense_layer<C, L::frag0(10), 9, 8, L::bias0(10)>(
+                ring, bias_lane, Bh, Bl,
+                [&](auto rt_, float4v (&acc)[NCT]) { store_act<C, decltype(rt_)::value, 4>(acc, Zh, Zl); });
+        }
+        dense_layer<C, L::frag0(11), 4, 1, L::bias0(11)>(ring, bias_lane, Zh, Zl, [&](auto, float4v (&acc)[NCT]) {
+            if (g == 0 && a.rgb) {
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    if (sidx[c] < a.M) {
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) a.rgb[sidx[c] * 3 + r] = 1.0f / (1.0f + expf(-acc[c][r]));
+                    }
+            }
+        });
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+static std::vector<LayerSpec> nerf_specs(const tgtc_linear* l) {
+    std::vector<LayerSpec> v;
+    auto add = [&](int idx, std::vector<Seg> segs) {
+        v.push_back(LayerSpec{l[idx].weight, l[idx].bias, l[idx].out_features, l[idx].in_features, std::move(segs)});
+    };
+    add(0, {{SEG_PE63, 0, 2}});
+    for (int i = 1; i <= 4; ++i) add(i, {{SEG_ACT, 0, 8}});
+    add(5, {{SEG_ACT, 63, 8}, {SEG_PE63, 0, 2}});  // reference column order: [pe(63) | h(256)]
+    add(6, {{SEG_ACT, 0, 8}});
+    add(7, {{SEG_ACT, 0, 8}});
+    add(8, {{SEG_ACT, 0, 8}});                       // sigma_layer
+    add(9, {{SEG_ACT, 0, 8}});                       // base_remap_layer
+    add(10, {{SEG_ACT, 0, 8}, {SEG_PE27, 256, 1}});  // rgb_layers.0 on [remap(256) | dirs(27)]
+    add(11, {{SEG_ACT, 0, 4}});                      // rgb_layers.1
+    return v;
+}
+
+// Measurement hook (bench.py): HIP events recorded on the launch stream around the next FULL / sigma-only
+// launch, so the kernel's duration is measured live inside the timed region.  Thread-local, one-shot.
+static thread_local hipEvent_t g_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+
+template <class C, int IN_MODE, bool FULL>
+static int launch_nerf(const NerfArgs& a, hipStream_t st) {
+    const long long nwg = (a.M + C::SAMPLES_PER_WG - 1) / C::SAMPLES_PER_WG;
+    if (a.M >= 0x7fffffffLL) return fail(TGTC_ERR_UNSUPPORTED, "nerf: too many samples in one launch (%lld)", a.M);
+    hipEvent_t* ev = g_ev[FULL ? 1 : 0];
+    if (ev[0]) TGTC_HIP_CHECK(hipEventRecord(ev[0], st));
+    nerf_mlp_kernel<C, IN_MODE, FULL><<<(unsigned)nwg, C::NWAVES * 64, 0, st>>>(a);
+    TGTC_LAUNCH_CHECK();
+    if (ev[1]) TGTC_HIP_CHECK(hipEventRecord(ev[1], st));
+    ev[0] = ev[1] = nullptr;
+    return TGTC_OK;
+}
+
+using CfgFast = MlpCfg<4, 4, false>;
+using CfgExact = MlpCfg<4, 2, true>;
+
+template <int IN_MODE, bool FULL>
+static int dispatch_nerf(const tgtc_net* net, NerfArgs& a, hipStream_t st) {
+    a.bias = net->dev;
+    a.stream = net->dev + net->bias_bytes;
+    if (net->precision == TGTC_PREC_FP16) return launch_nerf<CfgFast, IN_MODE, FULL>(a, st);
+    return launch_nerf<CfgExact, IN_MODE, FULL>(a, st);
+}
+
+int nerf_forward_rays_impl(const tgtc_net* net, const double* rays_o, const double* rays_d, const float* ts, int64_t R,
+                           int N, float* rgb, float* sigma, hipStream_t st) {
+    NerfArgs a{};
+    a.M = R * (int64_t)N, a.N = N, a.rays_o = rays_o, a.rays_d = rays_d, a.ts = ts, a.rgb = rgb, a.sigma = sigma;
+    return rgb ? dispatch_nerf<IN_RAYS, true>(net, a, st) : dispatch_nerf<IN_RAYS, false>(net, a, st);
+}
+
+}  // namespace tgtc
+
+using namespace tgtc;
+
+extern "C" int tgtc_nerf_create(const tgtc_linear* layers, int n_layers, int precision, tgtc_net** out) {
+    TGTC_REQUIRE(layers && out, "nerf_create: null argument");
+    TGTC_REQUIRE(precision == TGTC_PREC_FP16 || precision == TGTC_PREC_FP16X3, "nerf_create: unknown precision %d", precision);
+    static const int want[12][2] = {{256, 63},  {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 319},
+                                    {256, 256}, {256, 256}, {1, 256},   {256, 256}, {128, 283}, {3, 128}};
+    if (n_layers != 12) return fail(TGTC_ERR_UNSUPPORTED, "nerf_create: expected the 12 linears of MLP_style (D=8), got %d", n_layers);
+    for (int i = 0; i < 12; ++i) {
+        TGTC_REQUIRE(layers[i].weight && layers[i].bias, "nerf_create: layer %d has a null pointer", i);
+        if (layers[i].out_features != want[i][0] || layers[i].in_features != want[i][1])
+            return fail(TGTC_ERR_UNSUPPORTED, "nerf_create: layer %d is %dx%d, kernels are built for %dx%d (D=8, W=256, PE 10/4, viewdirs)",
+                        i, layers[i].out_features, layers[i].in_features, want[i][0], want[i][1]);
+    }
+    const bool split = precision == TGTC_PREC_FP16X3;
+    PackedNet p = pack_layers(nerf_specs(layers), split);
+    if (p.n_frags != NerfLayout::kFragsFull || (int)p.bias.size() != NerfLayout::kBiasFloats)
+        return fail(TGTC_ERR_UNSUPPORTED, "nerf_create: internal layout mismatch (%d frags, %zu bias)", p.n_frags, p.bias.size());
+    for (int i = 0; i < 12; ++i)
+        if (p.frag0[i] != NerfLayout::frag0(i) || p.bias0[i] != NerfLayout::bias0(i))
+            return fail(TGTC_ERR_UNSUPPORTED, "nerf_create: internal layout mismatch at layer %d", i);
+    tgtc_net* net = new tgtc_net();
+    net->kind = 0, net->precision = precision;
+    net->bias_bytes = kNerfBiasBytes;
+    net->stream_bytes = p.stream.size() * sizeof(half_t);
+    net->n_frags = p.n_frags;
+    // + one ring of slack so the last prefetches of a sigma-only pass never leave the allocation
+    const size_t total = net->bias_bytes + net->stream_bytes + kChunkBytes;
+    hipError_t e = hipMalloc((void**)&net->dev, total);
+    if (e != hipSuccess) {
+        delete net;
+        return fail(TGTC_ERR_HIP, "nerf_create: hipMalloc(%zu): %s", total, hipGetErrorString(e));
+    }
+    std::vector<char> host(total, 0);
+    memcpy(host.data(), p.bias.data(), p.bias.size() * sizeof(float));
+    memcpy(host.data() + net->bias_bytes, p.stream.data(), net->stream_bytes);
+    e = hipMemcpy(net->dev, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(net->dev);
+        delete net;
+        return fail(TGTC_ERR_HIP, "nerf_create: hipMemcpy: %s", hipGetErrorString(e));
+    }
+    *out = net;
+    return TGTC_OK;
+}
+
+extern "C" int tgtc_net_destroy(tgtc_net* net) {
+    if (!net) return TGTC_OK;
+    hipError_t e = net->dev ? hipFree(net->dev) : hipSuccess;
+    delete net;
+    if (e != hipSuccess) return fail(TGTC_ERR_HIP, "net_destroy: hipFree: %s", hipGetErrorString(e));
+    return TGTC_OK;
+}
+
+extern "C" int tgtc_time_next_nerf_launch(int full, void* start_event, void* stop_event) {
+    TGTC_REQUIRE(full == 0 || full == 1, "time_next_nerf_launch: full must be 0 (sigma-only) or 1");
+    g_ev[full][0] = reinterpret_cast<hipEvent_t>(start_event);
+    g_ev[full][1] = reinterpret_cast<hipEvent_t>(stop_event);
+    return TGTC_OK;
+}
+
+extern "C" int tgtc_net_precision(const tgtc_net* net) { return net ? net->precision : TGTC_ERR_ARG; }
+
+extern "C" int tgtc_nerf_forward(const tgtc_net* net, const double* pts, const double* dirs, int64_t M, float* rgb,
+                                 float* sigma, float* base_remap, float* pts_enc, float* dirs_enc, void* stream) {
+    TGTC_REQUIRE(net && net->kind == 0 && M >= 0, "nerf_forward: bad argument");
+    if (M == 0) return TGTC_OK;  // empty tensors carry null pointers
+    TGTC_REQUIRE(pts && dirs, "nerf_forward: null input");
+    NerfArgs a{};
+    a.M = M, a.pts = pts, a.dirs = dirs, a.rgb = rgb, a.sigma = sigma, a.remap = base_remap;
+    a.out_pts_enc = pts_enc, a.out_dirs_enc = dirs_enc;
+    return dispatch_nerf<IN_PTS, true>(net, a, as_stream(stream));
+}
+
+extern "C" int tgtc_nerf_mlp_forward(const tgtc_net* net, const float* pts_enc, const float* dirs_enc, int64_t M,
+                                     float* rgb, float* sigma, float* base_remap, void* stream) {
+    TGTC_REQUIRE(net && net->kind == 0 && M >= 0, "nerf_mlp_forward: bad argument");
+    if (M == 0) return TGTC_OK;
+    TGTC_REQUIRE(pts_enc && dirs_enc, "nerf_mlp_forward: null input");
+    NerfArgs a{};
+    a.M = M, a.pts_enc = pts_enc, a.dirs_enc = dirs_enc, a.rgb = rgb, a.sigma = sigma, a.remap = base_remap;
+    return dispatch_nerf<IN_ENC, true>(net, a, as_stream(stream));
+}
+
+extern "C" int tgtc_nerf_forward_rays(const tgtc_net* net, const double* rays_o, const double* rays_d, const float* ts,
+                                      int64_t R, int N, float* rgb, float* sigma, void* stream) {
+    TGTC_REQUIRE(net && net->kind == 0 && R >= 0 && N >= 1, "nerf_forward_rays: bad argument");
+    if (R == 0) return TGTC_OK;
+    TGTC_REQUIRE(rays_o && rays_d && ts && (rgb || sigma), "nerf_forward_rays: null input");
+    return nerf_forward_rays_impl(net, rays_o, rays_d, ts, R, N, rgb, sigma, as_stream(stream));
+}

@@ -1,0 +1,105 @@
+// Host-side weight packer: turns nn.Linear weights ([out,in] row-major fp32) into the
+// fragment-ordered fp16 (hi [+ lo]) stream the fused kernels consume through the LDS ring,
+// plus a padded fp32 bias table.  The k-slot -> input-column maps live in mlp_core.h.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "mlp_core.h"
+
+namespace tgtc {
+
+enum SegKind { SEG_ACT = 0, SEG_PE63 = 1, SEG_PE27 = 2, SEG_VEC32 = 3 };
+
+struct Seg {
+    SegKind kind;
+    int col0;    // first column of this source inside the reference's concatenated input
+    int ksteps;  // 32-deep k-steps this source occupies
+};
+
+struct LayerSpec {
+    const float* W;
+    const float* b;
+    int out, in;
+    std::vector<Seg> segs;
+    int ksteps() const {
+        int k = 0;
+        for (auto& s : segs) k += s.ksteps;
+        return k;
+    }
+    int row_tiles() const { return (out + 15) / 16; }
+};
+
+inline int seg_col(const Seg& s, int ks_in_seg, int g, int j) {
+    int c = -1;
+    switch (s.kind) {
+        case SEG_ACT: c = act_col(ks_in_seg, g, j); break;
+        case SEG_PE63: c = pe63_col(ks_in_seg, g, j); break;
+        case SEG_PE27: c = pe27_col(g, j); break;
+        case SEG_VEC32: c = vec32_col(g, j); break;
+    }
+    return c < 0 ? -1 : s.col0 + c;
+}
+
+struct PackedNet {
+    std::vector<half_t> stream;  // fragments, chunk-padded
+    std::vector<float> bias;     // 16 floats per row tile, layer after layer
+    std::vector<int> frag0;      // first fragment of each layer
+    std::vector<int> bias0;      // first bias float of each layer
+    int n_frags = 0;
+};
+
+inline PackedNet pack_layers(const std::vector<LayerSpec>& layers, bool split) {
+    PackedNet p;
+    const int frag_halves = kFragHalves * (split ? 2 : 1);
+    for (const LayerSpec& L : layers) {
+        p.frag0.push_back(p.n_frags);
+        p.bias0.push_back((int)p.bias.size());
+        const int RT = L.row_tiles();
+        for (int rt = 0; rt < RT; ++rt) {
+            for (int r = 0; r < 16; ++r) {
+                const int row = 16 * rt + r;
+                p.bias.push_back(row < L.out ? L.b[row] : 0.0f);
+            }
+            int ks = 0;
+            for (const Seg& s : L.segs) {
+                for (int k = 0; k < s.ksteps; ++k, ++ks) {
+                    const size_t base = p.stream.size();
+                    p.stream.resize(base + frag_halves, (half_t)0.0f);
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int m = lane & 15, g = lane >> 4, row = 16 * rt + m;
+                        for (int j = 0; j < 8; ++j) {
+                            const int col = seg_col(s, k, g, j);
+                            float w = 0.0f;
+                            if (row < L.out && col >= 0 && col < L.in) w = L.W[(size_t)row * L.in + col];
+                            const half_t hi = (half_t)w;
+                            p.stream[base + lane * 8 + j] = hi;
+                            if (split) p.stream[base + kFragHalves + lane * 8 + j] = (half_t)(w - (float)hi);
+                        }
+                    }
+                    ++p.n_frags;
+                }
+            }
+        }
+    }
+    const size_t chunk_halves = kChunkBytes / sizeof(half_t);
+    p.stream.resize((p.stream.size() + chunk_halves - 1) / chunk_halves * chunk_halves, (half_t)0.0f);
+    return p;
+}
+
+}  // namespace tgtc
+
+// The opaque handle of the C ABI.
+struct tgtc_net {
+    int kind;        // 0 = NeRF (StyleNerf), 1 = style pair (concat MLP + style MLP)
+    int precision;   // TGTC_PREC_*
+    char* dev;       // one device allocation: [bias table, padded][weight stream]
+    size_t bias_bytes;
+    size_t stream_bytes;
+    int n_frags;
+    // style pair only: second stream (the style MLP) inside the same allocation
+    size_t bias2_off, bias2_bytes, stream2_off, stream2_bytes;
+    int n_frags2;
+};

@@ -1,0 +1,77 @@
+// Fused render chains: the reference's per-batch sequence of callables collapsed into one host call
+// that enqueues the kernels back to back on one stream (no host sync, no allocation).
+//   plain : rendering.py:27-51   (cal_geometry)
+//   styled: rendering.py:118-178 (render_style)   -- see mlp_style.hip
+#include "common.h"
+
+struct tgtc_net;
+
+namespace tgtc {
+int launch_composite(const float* rgb, const float* sigma, const float* ts, int64_t R, int N, float* rgb_exp,
+                     float* t_exp, float* weights, hipStream_t st);
+int launch_sample_fine(const double* rays_o, const double* rays_d, const float* ts, const float* weights, int64_t R,
+                       int N, int n_fine, double* pts_out, float* ts_out, hipStream_t st);
+int nerf_forward_rays_impl(const tgtc_net* net, const double* rays_o, const double* rays_d, const float* ts, int64_t R,
+                           int N, float* rgb, float* sigma, hipStream_t st);
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct RenderWorkspace {
+    float *ts_c, *sigma_c, *rgb_c, *w_c, *ts_f, *sigma_f, *rgb_f;
+    size_t total;
+    RenderWorkspace(char* base, int64_t R, int nc, int nf) {
+        const int nt = nc + nf;
+        size_t off = 0;
+        auto take = [&](size_t floats) {
+            float* p = reinterpret_cast<float*>(base + off);
+            off += align256(floats * sizeof(float));
+            return p;
+        };
+        ts_c = take((size_t)R * nc);
+        sigma_c = take((size_t)R * nc);
+        rgb_c = take((size_t)R * nc * 3);
+        w_c = take((size_t)R * nc);
+        ts_f = take((size_t)R * nt);
+        sigma_f = take((size_t)R * nt);
+        rgb_f = take((size_t)R * nt * 3);
+        total = off;
+    }
+};
+}  // namespace tgtc
+
+using namespace tgtc;
+
+extern "C" size_t tgtc_render_workspace_bytes(int64_t R, int n_coarse, int n_fine) {
+    if (R < 0 || n_coarse < 0 || n_fine < 0) return 0;
+    return RenderWorkspace(nullptr, R, n_coarse, n_fine).total;
+}
+
+extern "C" int tgtc_render_rays_plain(const tgtc_net* coarse, const tgtc_net* fine, const double* rays_o,
+                                      const double* rays_d, int64_t R, int n_coarse, int n_fine, float near_,
+                                      float far_, const float* jitter, void* workspace, size_t workspace_bytes,
+                                      float* rgb_fine, float* t_fine, float* rgb_coarse, float* t_coarse,
+                                      void* stream) {
+    TGTC_REQUIRE(coarse && fine && R >= 0, "render_rays_plain: bad argument");
+    // the reference dereferences None when N_samples_fine == 0; require it instead
+    TGTC_REQUIRE(n_coarse >= 3 && n_fine >= 1, "render_rays_plain: need n_coarse >= 3 and n_fine >= 1 (got %d, %d)",
+                 n_coarse, n_fine);
+    if (R == 0) return TGTC_OK;
+    TGTC_REQUIRE(rays_o && rays_d && workspace && rgb_fine && t_fine, "render_rays_plain: null pointer");
+    RenderWorkspace ws(static_cast<char*>(workspace), R, n_coarse, n_fine);
+    TGTC_REQUIRE(workspace_bytes >= ws.total, "render_rays_plain: workspace of %zu bytes, need %zu", workspace_bytes,
+                 ws.total);
+    hipStream_t st = as_stream(stream);
+    int rc = tgtc_sample_coarse(rays_o, rays_d, R, n_coarse, near_, far_, jitter, nullptr, ws.ts_c, stream);
+    if (rc) return rc;
+    // coarse pass: only the weights are consumed unless the caller asks for the coarse image
+    float* rgb_c = rgb_coarse ? ws.rgb_c : nullptr;
+    rc = nerf_forward_rays_impl(coarse, rays_o, rays_d, ws.ts_c, R, n_coarse, rgb_c, ws.sigma_c, st);
+    if (rc) return rc;
+    rc = launch_composite(rgb_c, ws.sigma_c, ws.ts_c, R, n_coarse, rgb_coarse, t_coarse, ws.w_c, st);
+    if (rc) return rc;
+    rc = launch_sample_fine(rays_o, rays_d, ws.ts_c, ws.w_c, R, n_coarse, n_fine, nullptr, ws.ts_f, st);
+    if (rc) return rc;
+    rc = nerf_forward_rays_impl(fine, rays_o, rays_d, ws.ts_f, R, n_coarse + n_fine, ws.rgb_f, ws.sigma_f, st);
+    if (rc) return rc;
+    return launch_composite(ws.rgb_f, ws.sigma_f, ws.ts_f, R, n_coarse + n_fine, rgb_fine, t_fine, nullptr, st);
+}

@@ -1,0 +1,183 @@
+"""Neural operators with the reference's `models.py` class names, constructor arguments, forward
+keyword signatures, returned dict keys and state-dict key names -- evaluated by the HIP library.
+
+reference: models.py:24-60 (Embedder), :63-117 (MLP_style), :120-147 (StyleMLP_before_concat),
+:149-180 (StyleMLP_Wild_multilayers), :182-223 (StyleNerf), :475-506 (StyleLatents_variational).
+
+The modules own ordinary `nn.Parameter`s under the reference's names (so reference checkpoints
+`load_state_dict` directly); the packed fp16 weight stream the kernels read is (re)built lazily
+whenever the parameters change.  Forward only: the reference's render paths never backpropagate.
+Select the arithmetic mode with `args.precision` = 'fp16x3' (default, fp32-equivalent) or 'fp16'.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import hip
+
+
+class Embedder(nn.Module):
+    """reference models.py:24-60 (log-sampled bands, include_input, sin/cos)."""
+
+    def __init__(self, input_dim, max_freq_log2, N_freqs, log_sampling=True, include_input=True):
+        super().__init__()
+        if not (log_sampling and include_input and input_dim == 3 and max_freq_log2 == N_freqs - 1):
+            raise NotImplementedError("the HIP encoder implements the reference's only configuration: "
+                                      "3-d input, bands 2^0..2^(L-1), include_input")
+        self.input_dim, self.N_freqs = input_dim, N_freqs
+        self.out_dim = input_dim * (1 + 2 * N_freqs)
+
+    def forward(self, x):
+        hip.require_gpu(x)
+        lib = hip.load()
+        lead = x.shape[:-1]
+        is64 = x.dtype == torch.float64
+        flat = x.reshape(-1, 3).to(torch.float64 if is64 else torch.float32).contiguous()
+        out = torch.empty(flat.shape[0], self.out_dim, device=x.device, dtype=torch.float32)
+        hip.check(lib.tgtc_posenc(hip.ptr(flat), int(is64), flat.shape[0], self.N_freqs, hip.ptr(out), hip.stream()))
+        # the reference returns the input dtype and StyleNerf casts to float32 (models.py:219-220)
+        return out.reshape(*lead, self.out_dim)
+
+
+class _Packed(nn.Module):
+    """Caches a device-resident packed copy of the parameters; invalidated when they change."""
+
+    def __init__(self):
+        super().__init__()
+        self._net = None
+        self._net_key = None
+        self.precision = "fp16x3"
+
+    def _param_key(self):
+        return (self.precision,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _packed(self):
+        key = self._param_key()
+        if self._net is None or key != self._net_key:
+            self._net = self._pack()
+            self._net_key = key
+        return self._net
+
+
+class MLP_style(_Packed):
+    """reference models.py:63-117 (D=8, W=256, skips=[4], ReLU, view-dependent colour)."""
+
+    def __init__(self, D=8, W=256, input_ch=63, input_ch_viewdirs=27, skips=(4,), act_func=nn.ReLU, use_viewdir=True,
+                 sigma_mul=0., enable_style=False):
+        super().__init__()
+        self.input_ch, self.input_ch_viewdirs, self.skips = input_ch, input_ch_viewdirs, list(skips)
+        self.use_viewdir, self.sigma_mul, self.enable_style = use_viewdir, sigma_mul, enable_style
+        layers, dim = [], input_ch
+        for i in range(D):
+            layers.append(nn.Linear(dim, W))
+            dim = W
+            if i in self.skips and i != D - 1:
+                dim += input_ch
+        self.base_layers = nn.ModuleList(layers)
+        self.sigma_layer = nn.Linear(dim, 1)
+        self.base_remap_layer = nn.Linear(dim, 256)
+        d = 256 + input_ch_viewdirs if use_viewdir else 256
+        self.rgb_layers = nn.ModuleList([nn.Linear(d, W // 2), nn.Linear(W // 2, 3)])
+        if act_func is not nn.ReLU or sigma_mul != 0.:
+            raise NotImplementedError("HIP kernels implement the ReLU network (act_type=relu)")
+
+    def _pack(self):
+        return hip.nerf_create(self.state_dict(), self.precision, prefix="")
+
+    def forward(self, **kwargs):
+        """pts [..,63], dirs [..,27] float32 (already encoded) -> dict rgb, base_remap, pts, sigma."""
+        pts, dirs = kwargs['pts'], kwargs['dirs']
+        hip.require_gpu(pts, dirs)
+        lib = hip.load()
+        lead = pts.shape[:-1]
+        p = pts.reshape(-1, self.input_ch).to(torch.float32).contiguous()
+        d = dirs.reshape(-1, self.input_ch_viewdirs).to(torch.float32).contiguous()
+        M = p.shape[0]
+        rgb = torch.empty(M, 3, device=p.device, dtype=torch.float32)
+        sigma = torch.empty(M, device=p.device, dtype=torch.float32)
+        remap = torch.empty(M, 256, device=p.device, dtype=torch.float32)
+        hip.check(lib.tgtc_nerf_mlp_forward(self._packed().handle, hip.ptr(p), hip.ptr(d), M, hip.ptr(rgb),
+                                            hip.ptr(sigma), hip.ptr(remap), hip.stream()))
+        return OrderedDict([('rgb', rgb.reshape(*lead, 3)), ('base_remap', remap.reshape(*lead, 256)),
+                            ('pts', pts), ('sigma', sigma.reshape(*lead))])
+
+
+class StyleNerf(nn.Module):
+    """reference models.py:182-223."""
+
+    def __init__(self, args, mode='coarse', enable_style=False):
+        super().__init__()
+        self.use_viewdir = args.use_viewdir
+        if getattr(args, 'act_type', 'relu') != 'relu':
+            raise NotImplementedError("HIP kernels implement act_type=relu (the shipped configs)")
+        self.is_siren = False
+        self.embedder_coor = Embedder(3, args.embed_freq_coor - 1, args.embed_freq_coor)
+        self.embedder_dir = Embedder(3, args.embed_freq_dir - 1, args.embed_freq_dir)
+        depth, width = ((args.netdepth, args.netwidth) if mode == 'coarse'
+                        else (args.netdepth_fine, args.netwidth_fine))
+        self.net = MLP_style(D=depth, W=width, input_ch=self.embedder_coor.out_dim,
+                             input_ch_viewdirs=self.embedder_dir.out_dim, skips=[4], use_viewdir=self.use_viewdir,
+                             enable_style=enable_style)
+        self.net.precision = getattr(args, 'precision', 'fp16x3')
+        self.enable_style = enable_style
+
+    def set_enable_style(self, enable_style=False):
+        self.enable_style = enable_style
+        self.net.enable_style = enable_style
+
+    def packed(self):
+        return self.net._packed()
+
+    def forward(self, **kwargs):
+        """pts, dirs [..,3] (float64 in the render path) -> dict rgb, base_remap, pts (encoded), sigma, dirs (encoded)."""
+        pts, dirs = kwargs['pts'], kwargs['dirs']
+        hip.require_gpu(pts)
+        lib = hip.load()
+        lead = pts.shape[:-1]
+        p = pts.reshape(-1, 3).to(torch.float64).contiguous()
+        d = dirs.expand(*lead, 3).reshape(-1, 3).to(torch.float64).contiguous()
+        M = p.shape[0]
+        dev = p.device
+        rgb = torch.empty(M, 3, device=dev, dtype=torch.float32)
+        sigma = torch.empty(M, device=dev, dtype=torch.float32)
+        remap = torch.empty(M, 256, device=dev, dtype=torch.float32)
+        pe = torch.empty(M, self.embedder_coor.out_dim, device=dev, dtype=torch.float32)
+        de = torch.empty(M, self.embedder_dir.out_dim, device=dev, dtype=torch.float32)
+        hip.check(lib.tgtc_nerf_forward(self.packed().handle, hip.ptr(p), hip.ptr(d), M, hip.ptr(rgb), hip.ptr(sigma),
+                                        hip.ptr(remap), hip.ptr(pe), hip.ptr(de), hip.stream()))
+        return OrderedDict([('rgb', rgb.reshape(*lead, 3)), ('base_remap', remap.reshape(*lead, 256)),
+                            ('pts', pe.reshape(*lead, self.embedder_coor.out_dim)), ('sigma', sigma.reshape(*lead)),
+                            ('dirs', de.reshape(*lead, self.embedder_dir.out_dim))])
+
+
+class StyleLatents_variational(nn.Module):
+    """reference models.py:475-506."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.style_num, self.frame_num, self.latent_dim = kwargs['style_num'], kwargs['frame_num'], kwargs['latent_dim']
+        self.latents = nn.Parameter(torch.randn(self.style_num, self.frame_num, self.latent_dim))
+        self.style_latents_mu = nn.Parameter(torch.randn(self.style_num, self.latent_dim))
+        self.style_latents_logvar = nn.Parameter(torch.randn(self.style_num, self.latent_dim))
+        self.sigma_scale = 1.
+
+    def forward(self, **kwargs):
+        style_ids, frame_ids = kwargs['style_ids'], kwargs['frame_ids']
+        hip.require_gpu(self.latents)
+        lib = hip.load()
+        dev = self.latents.device
+        sid = style_ids.to(device=dev, dtype=torch.int64).contiguous()
+        fid = frame_ids.to(device=dev, dtype=torch.int64).contiguous()
+        tile7 = kwargs.get('type', 'llff') == 'llff'
+        rows = self.style_num * self.frame_num
+        flat = sid * self.frame_num + fid
+        limit = 7 * rows if tile7 else rows
+        if flat.numel() and (int(flat.max()) >= limit or int(flat.min()) < 0):
+            raise IndexError("latent index out of range (%d rows%s)" % (rows, ", tiled x7" if tile7 else ""))
+        out = torch.empty(sid.shape[0], self.latent_dim, device=dev, dtype=torch.float32)
+        hip.check(lib.tgtc_latents_forward(hip.ptr(self.latents.detach().contiguous()),
+                                           hip.ptr(self.style_latents_mu.detach().contiguous()), self.style_num,
+                                           self.frame_num, self.latent_dim, hip.ptr(sid), hip.ptr(fid), sid.shape[0],
+                                           float(self.sigma_scale), int(tile7), hip.ptr(out), hip.stream()))
+        return out

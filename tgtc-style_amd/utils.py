@@ -1,0 +1,110 @@
+"""Per-ray operators with the reference's `utils.py` names and call signatures, backed by the HIP
+library (reference utils.py:354-386, :435-456, :509-531, :573-609).
+
+Inputs are CUDA/HIP tensors; outputs are freshly allocated tensors, as in the reference.  There is
+no CPU implementation here: without a GPU or without libtgtc_hip.so these functions raise.
+"""
+import torch
+
+from . import hip
+
+
+def _f64(t):
+    return t.to(torch.float64).contiguous()
+
+
+def _f32(t):
+    return t.to(torch.float32).contiguous()
+
+
+def sampling_pts_uniform(rays_o, rays_d, N_samples=64, near=0., far=1.05, harmony=False, perturb=False, jitter=None):
+    """reference utils.py:509-531.  Returns (pts [R,N,3] float64, ts [R,N] float32).
+
+    `perturb=True` draws the stratified jitter with torch.rand on the device (the reference uses
+    nn.init.uniform_, utils.py:519-520); pass `jitter` ([R,N] in [0,1)) to make it reproducible.
+    """
+    if harmony:
+        raise NotImplementedError("harmony (inverse-depth) sampling is unused by the reference render paths")
+    hip.require_gpu(rays_o, rays_d)
+    lib = hip.load()
+    rays_o, rays_d = _f64(rays_o), _f64(rays_d)
+    R = rays_o.shape[0]
+    if perturb and jitter is None:
+        jitter = torch.rand(R, N_samples, device=rays_o.device, dtype=torch.float32)
+    if jitter is not None:
+        jitter = _f32(jitter)
+        assert jitter.shape == (R, N_samples)
+    pts = torch.empty(R, N_samples, 3, device=rays_o.device, dtype=torch.float64)
+    ts = torch.empty(R, N_samples, device=rays_o.device, dtype=torch.float32)
+    hip.check(lib.tgtc_sample_coarse(hip.ptr(rays_o), hip.ptr(rays_d), R, N_samples, float(near), float(far),
+                                     hip.ptr(jitter), hip.ptr(pts), hip.ptr(ts), hip.stream()))
+    return pts, ts
+
+
+def sampling_pts_fine_torch(rays_o, rays_d, ts, weights, N_samples_fine=64):
+    """reference utils.py:573-580 (deterministic inverse-CDF + sorted merge).
+    Returns (pts [R,N+Nf,3] float64, t_vals [R,N+Nf] float32 ascending)."""
+    hip.require_gpu(rays_o, rays_d, ts, weights)
+    lib = hip.load()
+    rays_o, rays_d, ts, weights = _f64(rays_o), _f64(rays_d), _f32(ts), _f32(weights)
+    R, N = ts.shape
+    T = N + N_samples_fine
+    pts = torch.empty(R, T, 3, device=ts.device, dtype=torch.float64)
+    tv = torch.empty(R, T, device=ts.device, dtype=torch.float32)
+    hip.check(lib.tgtc_sample_fine(hip.ptr(rays_o), hip.ptr(rays_d), hip.ptr(ts), hip.ptr(weights), R, N,
+                                   N_samples_fine, hip.ptr(pts), hip.ptr(tv), hip.stream()))
+    return pts, tv
+
+
+def alpha_composition(pts_rgb, pts_sigma, t_values, sigma_noise_std=0., white_bkgd=False):
+    """reference utils.py:354-386.  Returns (rgb_exp [R,3], t_exp [R], weights [R,N])."""
+    hip.require_gpu(pts_rgb, pts_sigma, t_values)
+    lib = hip.load()
+    if sigma_noise_std > 0:
+        # training-time regulariser (utils.py:372-374); the render paths always pass 0
+        pts_sigma = pts_sigma + torch.randn_like(pts_sigma) * sigma_noise_std
+    rgb, sigma, ts = _f32(pts_rgb), _f32(pts_sigma), _f32(t_values)
+    R, N = sigma.shape
+    rgb_exp = torch.empty(R, 3, device=rgb.device, dtype=torch.float32)
+    t_exp = torch.empty(R, device=rgb.device, dtype=torch.float32)
+    w = torch.empty(R, N, device=rgb.device, dtype=torch.float32)
+    hip.check(lib.tgtc_composite(hip.ptr(rgb), hip.ptr(sigma), hip.ptr(ts), R, N, hip.ptr(rgb_exp), hip.ptr(t_exp),
+                                 hip.ptr(w), hip.stream()))
+    if white_bkgd:
+        rgb_exp = rgb_exp + (1. - w.sum(-1, keepdim=True))   # utils.py:383-384
+    return rgb_exp, t_exp, w
+
+
+def batchify(fn, chunk=1024 * 32):
+    """reference utils.py:435-456: split every kwarg on dim 0 into `chunk`-row pieces and concatenate
+    each entry of the returned dicts."""
+    if chunk is None:
+        return fn
+
+    def chunked(**kwargs):
+        first = next(iter(kwargs.values()))
+        pieces = {}
+        for lo in range(0, first.shape[0], chunk):
+            ret = fn(**{k: v[lo:lo + chunk] for k, v in kwargs.items()})
+            for k, v in ret.items():
+                pieces.setdefault(k, []).append(v)
+        return {k: torch.cat(v, 0) for k, v in pieces.items()}
+
+    return chunked
+
+
+def gen_rays(H, W, focal, c2w, first_pixel=0, n=None, pixel_alignment=False, ndc=True, ndc_near=1.0, device="cuda"):
+    """Rays of pixels [first_pixel, first_pixel+n) of an H x W frame on the device: reference
+    dataset.py:33-42 + :44-61 with K = [[f,0,W/2],[0,f,H/2],[0,0,1]] (dataset.py:392-398).
+    Returns (rays_o, rays_d) float64 [n,3]."""
+    hip.require_gpu()
+    lib = hip.load()
+    import numpy as np
+    c2w = np.ascontiguousarray(np.asarray(c2w, dtype=np.float32)[:3, :4])
+    n = H * W - first_pixel if n is None else n
+    o = torch.empty(n, 3, device=device, dtype=torch.float64)
+    d = torch.empty(n, 3, device=device, dtype=torch.float64)
+    hip.check(lib.tgtc_gen_rays(H, W, float(focal), float(focal), 0.5 * W, 0.5 * H, c2w.ctypes.data,
+                                int(pixel_alignment), int(ndc), float(ndc_near), first_pixel, n, hip.ptr(o),
+                                hip.ptr(d), hip.stream()))
+    return o, d
