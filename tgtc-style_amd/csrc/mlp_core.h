@@ -66,16 +66,48 @@ struct MlpCfg {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Weight ring: NCHUNK chunks of the packed stream flow through kRingSlots LDS slots.
-// Protocol per chunk boundary (acquire<CH>): every wave waits (counted vmcnt) until ITS pieces of
-// chunk CH have landed, then the workgroup barrier makes the whole chunk visible; the barrier also
-// proves every wave is done with chunk CH-1, whose slot is the one chunk CH+DEPTH will overwrite.
-template <class C, int NCHUNK>
-struct WeightRing {
+// Weight stream: NCHUNK chunks of the packed fragment stream flow through kRingSlots LDS slots
+// (LDS-DMA, no VGPRs), and from there through a small register queue that runs PF fragments ahead of
+// the MFMAs that consume them.
+//
+// Ring protocol.  prologue() issues chunks 0..7.  start() waits (counted vmcnt) for this wave's pieces
+// of chunks 0 and 1 and joins the workgroup barrier.  On entering chunk CH >= 1 (boundary<CH>) a wave
+// waits for its pieces of chunk CH+1, joins the barrier -- which makes chunk CH+1 visible to every
+// wave and proves every wave is done with chunk CH-1 -- and then re-fills chunk CH-1's slot with chunk
+// CH+7.  Acquiring one chunk AHEAD lets the register queue read across chunk boundaries, so the MFMA
+// pipe never drains at a boundary.
+typedef __attribute__((address_space(3))) const char* lds_cptr;
+
+__device__ __forceinline__ lds_cptr opaque(lds_cptr p) {
+    // hide the constant relation between LDS base registers from the optimiser, so that every
+    // fragment read is `ds_read_b128 v, base offset:imm16` (no per-read address arithmetic)
+    unsigned a = (unsigned)(size_t)p;
+    asm volatile("" : "+v"(a));
+    return (lds_cptr)(size_t)a;
+}
+
+template <class C, int NFRAG>
+struct WeightStream {
+    static constexpr int NCHUNK = (NFRAG + C::FPC - 1) / C::FPC;
+    // LDS -> register staging in bursts of G fragments, double buffered: group g+1 is read while the
+    // MFMAs of group g run.  (hipcc only ever emits `s_waitcnt lgkmcnt(0)` here, never a counted wait,
+    // so each wait must find every outstanding read already old: one burst per group, issued right
+    // after the previous group's wait.)
+    static constexpr int G = C::SPLIT ? 2 : 4;
+    static_assert(C::FPC % G == 0 && 2 * G <= C::FPC, "groups must tile a chunk and stay within one chunk of look-ahead");
+
     const char* src;   // per-lane: stream + wave*GPC*1024 + lane*16
     char* lds_wave;    // wave-uniform: ring + wave*GPC*1024
-    const char* lds_lane;  // per-lane read base: ring + lane*16
+    lds_cptr lane_lo;  // ring + lane*16            (ring bytes [0, 64K))
+    lds_cptr lane_hi;  // ring + 65536 + lane*16    (ring bytes [64K, 128K))
+    half8 qh[2][G], ql[2][G];
 
+    __device__ __forceinline__ void init(const char* stream, char* smem, int wave, int lane) {
+        src = stream + wave * (C::GPC * 1024) + lane * 16;
+        lds_wave = smem + wave * (C::GPC * 1024);
+        lane_lo = opaque((lds_cptr)smem + lane * 16);
+        lane_hi = opaque((lds_cptr)smem + 65536 + lane * 16);
+    }
     template <int CH>
     __device__ __forceinline__ void issue() const {
         if constexpr (CH < NCHUNK) {
@@ -87,19 +119,55 @@ struct WeightRing {
         }
     }
     __device__ __forceinline__ void prologue() const {
-        static_for<kPrefetchDepth>([&](auto ch) { issue<ch>(); });
-    }
-    template <int CH>
-    __device__ __forceinline__ void acquire() const {
-        constexpr int last = (CH + kPrefetchDepth - 1 < NCHUNK - 1) ? CH + kPrefetchDepth - 1 : NCHUNK - 1;
-        wait_vmcnt<(last - CH) * C::GPC>();
-        __builtin_amdgcn_s_barrier();
-        issue<CH + kPrefetchDepth>();
+        static_for<kRingSlots>([&](auto ch) { issue<decltype(ch)::value>(); });
     }
     template <int FRAG, int PART>
     __device__ __forceinline__ half8 read() const {
         constexpr int off = ((FRAG / C::FPC) % kRingSlots) * kChunkBytes + (FRAG % C::FPC) * C::FRAG_BYTES + PART * 1024;
-        return *reinterpret_cast<const half8*>(lds_lane + off);
+        typedef __attribute__((address_space(3))) const half8* lds_h8;
+        if constexpr (off < 65536) return *(lds_h8)(lane_lo + off);
+        else return *(lds_h8)(lane_hi + (off - 65536));
+    }
+    template <int F>
+    __device__ __forceinline__ void fetch() {
+        if constexpr (F < NFRAG) {
+            qh[(F / G) & 1][F % G] = read<F, 0>();
+            if constexpr (C::SPLIT) ql[(F / G) & 1][F % G] = read<F, 1>();
+        }
+    }
+    __device__ __forceinline__ void start() {
+        constexpr int issued_last = (kRingSlots - 1 < NCHUNK - 1) ? kRingSlots - 1 : NCHUNK - 1;
+        constexpr int need = NCHUNK > 1 ? 1 : 0;
+        wait_vmcnt<(issued_last - need) * C::GPC>();
+        __builtin_amdgcn_s_barrier();
+        static_for<G>([&](auto f) { fetch<decltype(f)::value>(); });
+    }
+    template <int CH>
+    __device__ __forceinline__ void boundary() const {
+        if constexpr (CH + 1 < NCHUNK) {
+            constexpr int issued_last = (CH + kRingSlots - 2 < NCHUNK - 1) ? CH + kRingSlots - 2 : NCHUNK - 1;
+            wait_vmcnt<(issued_last - (CH + 1)) * C::GPC>();
+            __builtin_amdgcn_s_barrier();
+            issue<CH + kRingSlots - 1>();
+        }
+    }
+    // fragment F (hi [+lo]).  On the first fragment of a group: retire the group's reads, then launch
+    // the next group's burst into the other buffer.
+    template <int F>
+    __device__ __forceinline__ void get(half8& ah, half8& al) {
+        constexpr int buf = (F / G) & 1, k = F % G;
+        if constexpr (k == 0) {
+            if constexpr (F % C::FPC == 0 && F > 0) boundary<F / C::FPC>();
+#pragma unroll
+            for (int j = 0; j < G; ++j) {  // a "use": the compiler's lgkmcnt wait lands HERE, before the burst
+                asm volatile("" ::"v"(qh[buf][j]));
+                if constexpr (C::SPLIT) asm volatile("" ::"v"(ql[buf][j]));
+            }
+            static_for<G>([&](auto j) { fetch<F + G + decltype(j)::value>(); });
+        }
+        ah = qh[buf][k];
+        if constexpr (C::SPLIT) al = ql[buf][k];
+        __builtin_amdgcn_sched_barrier(0);  // pin: the burst stays ahead of this group's MFMAs
     }
 };
 
@@ -108,50 +176,64 @@ __device__ __forceinline__ float4v mfma16(half8 a, half8 b, float4v c) {
 }
 
 // One dense layer.  B operands: Bh[KS][NCT] (+ Bl in split mode).  Fragment (rt,ks) is stream
-// fragment FRAG0 + rt*KS + ks.  bias_lane points at (bias table) + 4*(lane>>4) floats in LDS.
-// epi(ic<rt>, acc[NCT]) receives the fp32 tile: rows 16*rt + 4*(lane>>4) + r, column = sample lane&15.
-template <class C, int FRAG0, int KS, int RT, int BIAS0, class RingT, class Epi>
-__device__ __forceinline__ void dense_layer(const RingT& ring, const float* bias_lane, const half8 (&Bh)[KS][C::NCT],
+// fragment FRAG0 + rt*KS + ks.  bias_lane = LDS address of (bias table) + 4*(lane>>4) floats.
+// epi(ic<rt>, ic<c>, acc) receives the fp32 tile of row tile rt, column tile c:
+//   rows 16*rt + 4*(lane>>4) + r (r = 0..3), column = sample lane&15.
+// The epilogue of row tile rt is issued, one column tile at a time, behind the first MFMAs of row
+// tile rt+1 (two accumulator sets), so its VALU work runs in the shadow of the matrix pipe.
+template <class C, int FRAG0, int KS, int RT, int BIAS0, class StreamT, class Epi>
+__device__ __forceinline__ void dense_layer(StreamT& st, lds_cptr bias_lane, const half8 (&Bh)[KS][C::NCT],
                                             const half8 (&Bl)[KS][C::NCT], Epi&& epi) {
+    constexpr int NCT = C::NCT;
+    constexpr int PER = (NCT + KS - 1) / KS;  // column tiles of the pending epilogue handled per k-step
+    typedef __attribute__((address_space(3))) const float4v* lds_f4;
+    float4v acc[2][NCT];
+    float4v bias[2];  // read one row tile ahead so that its wait never lands on a fresh burst
+    bias[0] = *(lds_f4)(bias_lane + BIAS0 * 4);
     static_for<RT>([&](auto rt_) {
         constexpr int rt = decltype(rt_)::value;
-        float4v acc[C::NCT];
-        const float4v b = *reinterpret_cast<const float4v*>(bias_lane + BIAS0 + 16 * rt);
+        constexpr int cur = rt & 1;
 #pragma unroll
-        for (int c = 0; c < C::NCT; ++c) acc[c] = b;
+        for (int c = 0; c < NCT; ++c) acc[cur][c] = bias[cur];
         static_for<KS>([&](auto ks_) {
             constexpr int ks = decltype(ks_)::value;
-            constexpr int frag = FRAG0 + rt * KS + ks;
-            if constexpr (frag % C::FPC == 0 && frag != 0) ring.template acquire<frag / C::FPC>();
-            const half8 ah = ring.template read<frag, 0>();
+            half8 ah, al;
+            st.template get<FRAG0 + rt * KS + ks>(ah, al);
+            if constexpr (ks == 0 && rt + 1 < RT) bias[cur ^ 1] = *(lds_f4)(bias_lane + (BIAS0 + 16 * (rt + 1)) * 4);
 #pragma unroll
-            for (int c = 0; c < C::NCT; ++c) acc[c] = mfma16(ah, Bh[ks][c], acc[c]);
+            for (int c = 0; c < NCT; ++c) acc[cur][c] = mfma16(ah, Bh[ks][c], acc[cur][c]);
             if constexpr (C::SPLIT) {
-                const half8 al = ring.template read<frag, 1>();
 #pragma unroll
-                for (int c = 0; c < C::NCT; ++c) acc[c] = mfma16(al, Bh[ks][c], acc[c]);
+                for (int c = 0; c < NCT; ++c) acc[cur][c] = mfma16(al, Bh[ks][c], acc[cur][c]);
 #pragma unroll
-                for (int c = 0; c < C::NCT; ++c) acc[c] = mfma16(ah, Bl[ks][c], acc[c]);
+                for (int c = 0; c < NCT; ++c) acc[cur][c] = mfma16(ah, Bl[ks][c], acc[cur][c]);
+            }
+            if constexpr (rt > 0) {
+                static_for<PER>([&](auto p_) {
+                    constexpr int c = ks * PER + decltype(p_)::value;
+                    if constexpr (c < NCT) epi(ic<rt - 1>{}, ic<c>{}, acc[cur ^ 1][c]);
+                });
             }
         });
-        epi(rt_, acc);
     });
+    static_for<NCT>([&](auto c_) { epi(ic<RT - 1>{}, c_, acc[(RT - 1) & 1][decltype(c_)::value]); });
 }
 
-// ReLU + fp16 (hi/lo) conversion of an accumulator tile into the next layer's B fragments:
+__device__ __forceinline__ float relu(float v) {
+    // integer max: one v_max_i32, no NaN-canonicalising v_max_f32 pair
+    return __builtin_bit_cast(float, max(__builtin_bit_cast(int, v), 0));
+}
+
+// ReLU + fp16 (hi/lo) conversion of one accumulator tile into the next layer's B fragment:
 // output row tile rt feeds k-step rt/2, elements (rt&1)*4 + r.
-template <class C, int RT_IDX, int KSN>
-__device__ __forceinline__ void store_act(const float4v (&acc)[C::NCT], half8 (&Yh)[KSN][C::NCT],
-                                          half8 (&Yl)[KSN][C::NCT]) {
+template <class C, int RT_IDX>
+__device__ __forceinline__ void store_act(const float4v& acc, half8& yh, half8& yl) {
 #pragma unroll
-    for (int c = 0; c < C::NCT; ++c) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v = fmaxf(acc[c][r], 0.0f);
-            const half_t h = (half_t)v;
-            Yh[RT_IDX / 2][c][(RT_IDX & 1) * 4 + r] = h;
-            if constexpr (C::SPLIT) Yl[RT_IDX / 2][c][(RT_IDX & 1) * 4 + r] = (half_t)(v - (float)h);
-        }
+    for (int r = 0; r < 4; ++r) {
+        const float v = relu(acc[r]);
+        const half_t h = (half_t)v;
+        yh[(RT_IDX & 1) * 4 + r] = h;
+        if constexpr (C::SPLIT) yl[(RT_IDX & 1) * 4 + r] = (half_t)(v - (float)h);
     }
 }
 

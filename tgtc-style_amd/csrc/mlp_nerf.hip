@@ -62,7 +62,6 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) nerf_mlp_kernel(NerfArgs a)
     constexpr int NCT = C::NCT;
     constexpr bool SPLIT = C::SPLIT;
     constexpr int NFRAG = FULL ? NerfLayout::kFragsFull : NerfLayout::kFragsSigma;
-    constexpr int NCHUNK = (NFRAG + C::FPC - 1) / C::FPC;
     using L = NerfLayout;
 
     // ALL LDS in one array (a second __shared__ object makes hipcc drain vmcnt before LDS reads).
@@ -112,16 +111,14 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) nerf_mlp_kernel(NerfArgs a)
         }
     }
 
-    // ---- 2. start the weight stream: bias table, then the first kPrefetchDepth chunks
-    WeightRing<C, NCHUNK> ring;
-    ring.src = a.stream + wave * (C::GPC * 1024) + lane * 16;
-    ring.lds_wave = smem + wave * (C::GPC * 1024);
-    ring.lds_lane = smem + lane * 16;
+    // ---- 2. start the weight stream: bias table, then the first 8 chunks
+    WeightStream<C, NFRAG> ws;
+    ws.init(a.stream, smem, wave, lane);
 #pragma unroll
     for (int j = 0; j < kNerfBiasBytes / (C::NWAVES * 1024); ++j)
         __builtin_amdgcn_global_load_lds(TGTC_GPTR(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16),
                                          TGTC_LPTR(smem + kRingBytes + (j * C::NWAVES + wave) * 1024), 16, 0, 0);
-    ring.prologue();
+    ws.prologue();
 
     // ---- 3. positional encoding into B fragments (overlaps the prefetch latency)
     if constexpr (IN_MODE != IN_ENC) {
@@ -138,19 +135,25 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) nerf_mlp_kernel(NerfArgs a)
         }
     }
 
-    const float* bias_lane = reinterpret_cast<const float*>(smem + kRingBytes) + 4 * g;
-    ring.template acquire<0>();
+    const lds_cptr bias_lane = opaque((lds_cptr)smem + kRingBytes + 16 * g);
+    ws.start();
 
     // ---- 4. trunk
     half8 Xh[8][NCT], Xl[8][NCT], Yh[8][NCT], Yl[8][NCT];
-    auto to_Y = [&](auto rt_, float4v (&acc)[NCT]) { store_act<C, decltype(rt_)::value, 8>(acc, Yh, Yl); };
-    auto to_X = [&](auto rt_, float4v (&acc)[NCT]) { store_act<C, decltype(rt_)::value, 8>(acc, Xh, Xl); };
+    auto to_Y = [&](auto rt_, auto c_, const float4v& acc) {
+        constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
+        store_act<C, rt>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
+    };
+    auto to_X = [&](auto rt_, auto c_, const float4v& acc) {
+        constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
+        store_act<C, rt>(acc, Xh[rt / 2][c], Xl[rt / 2][c]);
+    };
 
-    dense_layer<C, L::frag0(0), 2, 16, L::bias0(0)>(ring, bias_lane, pe_h, pe_l, to_Y);
-    dense_layer<C, L::frag0(1), 8, 16, L::bias0(1)>(ring, bias_lane, Yh, Yl, to_X);
-    dense_layer<C, L::frag0(2), 8, 16, L::bias0(2)>(ring, bias_lane, Xh, Xl, to_Y);
-    dense_layer<C, L::frag0(3), 8, 16, L::bias0(3)>(ring, bias_lane, Yh, Yl, to_X);
-    dense_layer<C, L::frag0(4), 8, 16, L::bias0(4)>(ring, bias_lane, Xh, Xl, to_Y);
+    dense_layer<C, L::frag0(0), 2, 16, L::bias0(0)>(ws, bias_lane, pe_h, pe_l, to_Y);
+    dense_layer<C, L::frag0(1), 8, 16, L::bias0(1)>(ws, bias_lane, Yh, Yl, to_X);
+    dense_layer<C, L::frag0(2), 8, 16, L::bias0(2)>(ws, bias_lane, Xh, Xl, to_Y);
+    dense_layer<C, L::frag0(3), 8, 16, L::bias0(3)>(ws, bias_lane, Yh, Yl, to_X);
+    dense_layer<C, L::frag0(4), 8, 16, L::bias0(4)>(ws, bias_lane, Xh, Xl, to_Y);
     {
         // skip layer: reference input is cat(pe, h) (models.py:98-99); k order here is [h | pe]
         half8 Bh[10][NCT], Bl[10][NCT];
@@ -160,34 +163,27 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) nerf_mlp_kernel(NerfArgs a)
             for (int k = 0; k < 8; ++k) Bh[k][c] = Yh[k][c], Bl[k][c] = Yl[k][c];
             Bh[8][c] = pe_h[0][c], Bh[9][c] = pe_h[1][c], Bl[8][c] = pe_l[0][c], Bl[9][c] = pe_l[1][c];
         }
-        dense_layer<C, L::frag0(5), 10, 16, L::bias0(5)>(ring, bias_lane, Bh, Bl, to_X);
+        dense_layer<C, L::frag0(5), 10, 16, L::bias0(5)>(ws, bias_lane, Bh, Bl, to_X);
     }
-    dense_layer<C, L::frag0(6), 8, 16, L::bias0(6)>(ring, bias_lane, Xh, Xl, to_Y);
-    dense_layer<C, L::frag0(7), 8, 16, L::bias0(7)>(ring, bias_lane, Yh, Yl, to_X);
+    dense_layer<C, L::frag0(6), 8, 16, L::bias0(6)>(ws, bias_lane, Xh, Xl, to_Y);
+    dense_layer<C, L::frag0(7), 8, 16, L::bias0(7)>(ws, bias_lane, Yh, Yl, to_X);
 
     // ---- 5. sigma head (models.py:103): row 0 of a 16-row tile -> lanes 0..15, register 0
-    dense_layer<C, L::frag0(8), 8, 1, L::bias0(8)>(ring, bias_lane, Xh, Xl, [&](auto, float4v (&acc)[NCT]) {
-        if (g == 0 && a.sigma) {
-#pragma unroll
-            for (int c = 0; c < NCT; ++c)
-                if (sidx[c] < a.M) a.sigma[sidx[c]] = acc[c][0];
-        }
+    dense_layer<C, L::frag0(8), 8, 1, L::bias0(8)>(ws, bias_lane, Xh, Xl, [&](auto, auto c_, const float4v& acc) {
+        constexpr int c = decltype(c_)::value;
+        if (g == 0 && a.sigma && sidx[c] < a.M) a.sigma[sidx[c]] = acc[0];
     });
 
     if constexpr (FULL) {
         // ---- 6. base_remap (models.py:106) and the colour head (models.py:107-111)
-        dense_layer<C, L::frag0(9), 8, 16, L::bias0(9)>(ring, bias_lane, Xh, Xl, [&](auto rt_, float4v (&acc)[NCT]) {
-            constexpr int rt = decltype(rt_)::value;
-            store_act<C, rt, 8>(acc, Yh, Yl);
-            if (a.remap) {
+        dense_layer<C, L::frag0(9), 8, 16, L::bias0(9)>(ws, bias_lane, Xh, Xl, [&](auto rt_, auto c_, const float4v& acc) {
+            constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
+            store_act<C, rt>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
+            if (a.remap && sidx[c] < a.M) {
+                float4v v;
 #pragma unroll
-                for (int c = 0; c < NCT; ++c)
-                    if (sidx[c] < a.M) {
-                        float4v v;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[c][r], 0.0f);
-                        *reinterpret_cast<float4v*>(a.remap + sidx[c] * 256 + 16 * rt + 4 * g) = v;
-                    }
+                for (int r = 0; r < 4; ++r) v[r] = relu(acc[r]);
+                *reinterpret_cast<float4v*>(a.remap + sidx[c] * 256 + 16 * rt + 4 * g) = v;
             }
         });
         half8 Zh[4][NCT], Zl[4][NCT];
@@ -199,18 +195,16 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) nerf_mlp_kernel(NerfArgs a)
                 for (int k = 0; k < 8; ++k) Bh[k][c] = Yh[k][c], Bl[k][c] = Yl[k][c];
                 Bh[8][c] = de_h[0][c], Bl[8][c] = de_l[0][c];
             }
-            dense_layer<C, L::frag0(10), 9, 8, L::bias0(10)>(
-                ring, bias_lane, Bh, Bl,
-                [&](auto rt_, float4v (&acc)[NCT]) { store_act<C, decltype(rt_)::value, 4>(acc, Zh, Zl); });
+            dense_layer<C, L::frag0(10), 9, 8, L::bias0(10)>(ws, bias_lane, Bh, Bl, [&](auto rt_, auto c_, const float4v& acc) {
+                constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
+                store_act<C, rt>(acc, Zh[rt / 2][c], Zl[rt / 2][c]);
+            });
         }
-        dense_layer<C, L::frag0(11), 4, 1, L::bias0(11)>(ring, bias_lane, Zh, Zl, [&](auto, float4v (&acc)[NCT]) {
-            if (g == 0 && a.rgb) {
+        dense_layer<C, L::frag0(11), 4, 1, L::bias0(11)>(ws, bias_lane, Zh, Zl, [&](auto, auto c_, const float4v& acc) {
+            constexpr int c = decltype(c_)::value;
+            if (g == 0 && a.rgb && sidx[c] < a.M) {
 #pragma unroll
-                for (int c = 0; c < NCT; ++c)
-                    if (sidx[c] < a.M) {
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) a.rgb[sidx[c] * 3 + r] = 1.0f / (1.0f + expf(-acc[c][r]));
-                    }
+                for (int r = 0; r < 3; ++r) a.rgb[sidx[c] * 3 + r] = 1.0f / (1.0f + expf(-acc[r]));
             }
         });
     }

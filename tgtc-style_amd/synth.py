@@ -16,8 +16,19 @@ PE_COOR = 63   # 3 + 3*2*10  (models.py:190-191)
 PE_DIR = 27    # 3 + 3*2*4   (models.py:192-193)
 LATENT = 32    # config.py:86
 HIDDEN_GAIN = math.sqrt(6.0)   # He-uniform: nn.Linear's default bound 1/sqrt(fan_in) x sqrt(6) keeps ReLU activations O(1)
-SIGMA_GAIN = 500.0             # sigma head scaled up (std ~100) so densities are peaky and the fine sampler is exercised
-SIGMA_SHIFT = -40.0            # ... and centred below zero so most samples are empty space (first hit varies per ray)
+SIGMA_GAIN = 500.0             # sigma head scaled up so densities are peaky and the fine sampler is exercised
+SIGMA_SHIFT = 20.0             # ... centred so ~30% of space is occupied and the first hit varies per ray
+PE_DECAY = 0.35                # input weights of band k scaled by 2^(-PE_DECAY*k): a 1/f^0.35-ish spectrum like a trained
+                               # NeRF's (spectral bias).  With PE_DECAY = 0 the density is white noise along a ray and the
+                               # coarse->fine chain amplifies 1e-6 perturbations to ~1e-3 (even fp32 vs fp64 of the reference).
+
+
+def _damp_pe(w, col0, decay, n_freqs=10):
+    """Scale the columns that multiply band k of a 63-wide point encoding starting at column col0."""
+    if decay:
+        for k in range(n_freqs):
+            w[:, col0 + 3 + 6 * k: col0 + 9 + 6 * k] *= np.float32(2.0 ** (-decay * k))
+    return w
 
 
 def _linear(rng, out_f, in_f, gain=1.0):
@@ -28,7 +39,7 @@ def _linear(rng, out_f, in_f, gain=1.0):
 
 
 def nerf_state(seed, depth=8, width=256, skips=(4,), use_viewdir=True, sigma_gain=SIGMA_GAIN,
-               sigma_shift=SIGMA_SHIFT, gain=HIDDEN_GAIN):
+               sigma_shift=SIGMA_SHIFT, gain=HIDDEN_GAIN, pe_decay=PE_DECAY):
     """StyleNerf state dict (keys `net.*`).  Shapes: models.py:76-93."""
     rng = np.random.default_rng(seed)
     sd, dim = {}, PE_COOR
@@ -46,10 +57,19 @@ def nerf_state(seed, depth=8, width=256, skips=(4,), use_viewdir=True, sigma_gai
     d = 256 + PE_DIR if use_viewdir else 256
     sd["net.rgb_layers.0.weight"], sd["net.rgb_layers.0.bias"] = _linear(rng, width // 2, d, gain)
     sd["net.rgb_layers.1.weight"], sd["net.rgb_layers.1.bias"] = _linear(rng, 3, width // 2, gain)
+    _damp_pe(sd["net.base_layers.0.weight"], 0, pe_decay)
+    for i in skips:
+        if i + 1 < depth:
+            _damp_pe(sd["net.base_layers.%d.weight" % (i + 1)], 0, pe_decay)   # cat(pe, h): pe first (models.py:98-99)
     return sd
 
 
-def concat_state(seed=2, style_D=8, width=256, skip=4, gain=HIDDEN_GAIN):
+def nerf_state_adversarial(seed):
+    """White-noise density (no spectral decay, mostly empty space): the ill-conditioned stress scene."""
+    return nerf_state(seed, sigma_shift=-40.0, pe_decay=0.0)
+
+
+def concat_state(seed=2, style_D=8, width=256, skip=4, gain=HIDDEN_GAIN, pe_decay=PE_DECAY):
     """StyleMLP_before_concat state dict (keys `layers.*`).  models.py:121-135: the loop breaks
     after appending the skip layer, so there are skip+1 layers."""
     rng = np.random.default_rng(seed)
@@ -58,13 +78,16 @@ def concat_state(seed=2, style_D=8, width=256, skip=4, gain=HIDDEN_GAIN):
         if i == skip:
             dim += PE_COOR
         sd["layers.%d.weight" % i], sd["layers.%d.bias" % i] = _linear(rng, width, dim, gain)
+        if i == 0:
+            _damp_pe(sd["layers.0.weight"], 0, pe_decay)                      # cat(x, latent)
         if i == skip:
+            _damp_pe(sd["layers.%d.weight" % i], width + LATENT, pe_decay)    # cat(h, latent, x)
             break
         dim = width + LATENT
     return sd
 
 
-def style_state(seed=3, style_D=8, width=256, skip=4, gain=HIDDEN_GAIN):
+def style_state(seed=3, style_D=8, width=256, skip=4, gain=HIDDEN_GAIN, pe_decay=PE_DECAY):
     """StyleMLP_Wild_multilayers state dict.  models.py:150-163."""
     rng = np.random.default_rng(seed)
     sd, dim = {}, PE_COOR + 512 + LATENT
@@ -72,6 +95,10 @@ def style_state(seed=3, style_D=8, width=256, skip=4, gain=HIDDEN_GAIN):
         if i == skip:
             dim += PE_COOR
         sd["layers.%d.weight" % i], sd["layers.%d.bias" % i] = _linear(rng, width, dim, gain)
+        if i == 0:
+            _damp_pe(sd["layers.0.weight"], 512, pe_decay)                    # cat(concated(512), x, latent)
+        if i == skip:
+            _damp_pe(sd["layers.%d.weight" % i], width + LATENT, pe_decay)    # cat(h, latent, x)
         dim = width + LATENT
     sd["layers.%d.weight" % (style_D - 1)], sd["layers.%d.bias" % (style_D - 1)] = _linear(rng, 3, width + LATENT, gain)
     return sd
