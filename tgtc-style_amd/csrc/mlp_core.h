@@ -86,8 +86,20 @@ __device__ __forceinline__ lds_cptr opaque(lds_cptr p) {
     return (lds_cptr)(size_t)a;
 }
 
-template <class C, int NFRAG>
+// Map: where the fragment stream comes from.  Map::NFRAG fragments in total, laid out as Map::NSEG
+// chunk-aligned segments; segment i covers chunks [Map::chunk0(i), Map::chunk0(i+1)) and is read from
+// its own device pointer (so one fused kernel can walk the concat-MLP, NeRF and style-MLP streams of
+// three separately packed handles back to back).
+template <int NFRAG_>
+struct SingleStreamMap {
+    static constexpr int NFRAG = NFRAG_;
+    static constexpr int NSEG = 1;
+    static constexpr int chunk0(int i) { return i == 0 ? 0 : (1 << 30); }
+};
+
+template <class C, class Map>
 struct WeightStream {
+    static constexpr int NFRAG = Map::NFRAG;
     static constexpr int NCHUNK = (NFRAG + C::FPC - 1) / C::FPC;
     // LDS -> register staging in bursts of G fragments, double buffered: group g+1 is read while the
     // MFMAs of group g run.  (hipcc only ever emits `s_waitcnt lgkmcnt(0)` here, never a counted wait,
@@ -96,24 +108,33 @@ struct WeightStream {
     static constexpr int G = C::SPLIT ? 2 : 4;
     static_assert(C::FPC % G == 0 && 2 * G <= C::FPC, "groups must tile a chunk and stay within one chunk of look-ahead");
 
-    const char* src;   // per-lane: stream + wave*GPC*1024 + lane*16
-    char* lds_wave;    // wave-uniform: ring + wave*GPC*1024
+    const char* src[Map::NSEG];  // per-lane: segment stream + wave*GPC*1024 + lane*16
+    char* lds_wave;              // wave-uniform: ring + wave*GPC*1024
     lds_cptr lane_lo;  // ring + lane*16            (ring bytes [0, 64K))
     lds_cptr lane_hi;  // ring + 65536 + lane*16    (ring bytes [64K, 128K))
     half8 qh[2][G], ql[2][G];
 
-    __device__ __forceinline__ void init(const char* stream, char* smem, int wave, int lane) {
-        src = stream + wave * (C::GPC * 1024) + lane * 16;
+    __device__ __forceinline__ void init(const char* const (&streams)[Map::NSEG], char* smem, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < Map::NSEG; ++i) src[i] = streams[i] + wave * (C::GPC * 1024) + lane * 16;
         lds_wave = smem + wave * (C::GPC * 1024);
         lane_lo = opaque((lds_cptr)smem + lane * 16);
         lane_hi = opaque((lds_cptr)smem + 65536 + lane * 16);
     }
+    static constexpr int seg_of(int ch) {
+        int s = 0;
+        for (int i = 1; i < Map::NSEG; ++i)
+            if (ch >= Map::chunk0(i)) s = i;
+        return s;
+    }
     template <int CH>
     __device__ __forceinline__ void issue() const {
         if constexpr (CH < NCHUNK) {
+            constexpr int seg = seg_of(CH);
+            constexpr size_t off = (size_t)(CH - Map::chunk0(seg)) * kChunkBytes;
 #pragma unroll
             for (int j = 0; j < C::GPC; ++j)
-                __builtin_amdgcn_global_load_lds(TGTC_GPTR(src + (size_t)CH * kChunkBytes + j * 1024),
+                __builtin_amdgcn_global_load_lds(TGTC_GPTR(src[seg] + off + j * 1024),
                                                  TGTC_LPTR(lds_wave + (CH % kRingSlots) * kChunkBytes + j * 1024),
                                                  16, 0, 0);
         }
@@ -168,6 +189,14 @@ struct WeightStream {
         ah = qh[buf][k];
         if constexpr (C::SPLIT) al = ql[buf][k];
         __builtin_amdgcn_sched_barrier(0);  // pin: the burst stays ahead of this group's MFMAs
+    }
+    // consume fragments [F0, F0+N) without using them (alignment gaps between segments)
+    template <int F0, int N>
+    __device__ __forceinline__ void skip() {
+        static_for<N>([&](auto i) {
+            half8 a, b;
+            get<F0 + decltype(i)::value>(a, b);
+        });
     }
 };
 

@@ -3,36 +3,9 @@
 // the [M,256] activations of the 11 dense layers never leave registers (mlp_core.h).
 #include "mlp_core.h"
 #include "mlp_pack.h"
+#include "mlp_layouts.h"
 
 namespace tgtc {
-
-// Stream order and compile-time fragment / bias bookkeeping (must match nerf_specs() below).
-//   layer      L0  L1  L2  L3  L4  L5  L6  L7  SIG REMAP C0  C1
-//   k-steps     2   8   8   8   8  10   8   8   8    8    9   4
-//   row tiles  16  16  16  16  16  16  16  16   1   16    8   1
-constexpr int kNerfKS[12] = {2, 8, 8, 8, 8, 10, 8, 8, 8, 8, 9, 4};
-constexpr int kNerfRT[12] = {16, 16, 16, 16, 16, 16, 16, 16, 1, 16, 8, 1};
-constexpr int nerf_frag0(int l) {
-    int f = 0;
-    for (int i = 0; i < l; ++i) f += kNerfKS[i] * kNerfRT[i];
-    return f;
-}
-constexpr int nerf_bias0(int l) {
-    int b = 0;
-    for (int i = 0; i < l; ++i) b += 16 * kNerfRT[i];
-    return b;
-}
-struct NerfLayout {
-    static constexpr int frag0(int l) { return nerf_frag0(l); }
-    static constexpr int bias0(int l) { return nerf_bias0(l); }
-    static constexpr int kFragsSigma = nerf_frag0(9);   // trunk + sigma head
-    static constexpr int kFragsFull = nerf_frag0(12);   // 1172
-    static constexpr int kBiasFloats = nerf_bias0(12);  // 2464
-};
-
-constexpr int kNerfBiasBytes = 12288;  // 2464 floats padded to a multiple of 4 KiB (4 waves x 1 KiB LDS-DMA)
-static_assert(NerfLayout::kBiasFloats * 4 <= kNerfBiasBytes, "bias table");
-static_assert(NerfLayout::kFragsFull == 1172, "fragment count");
 
 enum InMode { IN_RAYS = 0, IN_PTS = 1, IN_ENC = 2 };
 
@@ -112,8 +85,9 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) nerf_mlp_kernel(NerfArgs a)
     }
 
     // ---- 2. start the weight stream: bias table, then the first 8 chunks
-    WeightStream<C, NFRAG> ws;
-    ws.init(a.stream, smem, wave, lane);
+    WeightStream<C, SingleStreamMap<NFRAG>> ws;
+    const char* const streams[1] = {a.stream};
+    ws.init(streams, smem, wave, lane);
 #pragma unroll
     for (int j = 0; j < kNerfBiasBytes / (C::NWAVES * 1024); ++j)
         __builtin_amdgcn_global_load_lds(TGTC_GPTR(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16),

@@ -102,4 +102,6 @@ struct tgtc_net {
     // style pair only: second stream (the style MLP) inside the same allocation
     size_t bias2_off, bias2_bytes, stream2_off, stream2_bytes;
     int n_frags2;
+    size_t stash_off;  // per-workgroup scratch slabs of the fused stylised kernel
+    int n_wg;          // persistent grid size (= CUs)
 };

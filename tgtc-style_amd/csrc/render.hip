@@ -14,6 +14,10 @@ int launch_sample_fine(const double* rays_o, const double* rays_d, const float* 
 int nerf_forward_rays_impl(const tgtc_net* net, const double* rays_o, const double* rays_d, const float* ts, int64_t R,
                            int N, float* rgb, float* sigma, hipStream_t st);
 
+int styled_forward_rays_impl(const tgtc_net* nerf, const tgtc_net* style, const double* rays_o, const double* rays_d,
+                             const float* ts, const float* z, int64_t R, int N, float* rgb, float* sigma,
+                             hipStream_t st);
+
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct RenderWorkspace {
@@ -72,6 +76,40 @@ extern "C" int tgtc_render_rays_plain(const tgtc_net* coarse, const tgtc_net* fi
     rc = launch_sample_fine(rays_o, rays_d, ws.ts_c, ws.w_c, R, n_coarse, n_fine, nullptr, ws.ts_f, st);
     if (rc) return rc;
     rc = nerf_forward_rays_impl(fine, rays_o, rays_d, ws.ts_f, R, n_coarse + n_fine, ws.rgb_f, ws.sigma_f, st);
+    if (rc) return rc;
+    return launch_composite(ws.rgb_f, ws.sigma_f, ws.ts_f, R, n_coarse + n_fine, rgb_fine, t_fine, nullptr, st);
+}
+
+// rendering.py:118-178 (render_style): like the plain chain, with the stylised colour on both passes.
+// The coarse colours only matter if the caller asks for the coarse image: the fine sampler consumes the
+// weights, which depend on sigma alone, so by default the coarse pass runs the sigma-only NeRF kernel.
+extern "C" int tgtc_render_rays_styled(const tgtc_net* coarse, const tgtc_net* fine, const tgtc_net* style,
+                                       const double* rays_o, const double* rays_d, const float* z, int64_t R,
+                                       int n_coarse, int n_fine, float near_, float far_, const float* jitter,
+                                       void* workspace, size_t workspace_bytes, float* rgb_fine, float* t_fine,
+                                       float* rgb_coarse, float* t_coarse, void* stream) {
+    TGTC_REQUIRE(coarse && fine && style && R >= 0, "render_rays_styled: bad argument");
+    TGTC_REQUIRE(n_coarse >= 3 && n_fine >= 1, "render_rays_styled: need n_coarse >= 3 and n_fine >= 1 (got %d, %d)",
+                 n_coarse, n_fine);
+    if (R == 0) return TGTC_OK;
+    TGTC_REQUIRE(rays_o && rays_d && z && workspace && rgb_fine && t_fine, "render_rays_styled: null pointer");
+    RenderWorkspace ws(static_cast<char*>(workspace), R, n_coarse, n_fine);
+    TGTC_REQUIRE(workspace_bytes >= ws.total, "render_rays_styled: workspace of %zu bytes, need %zu", workspace_bytes,
+                 ws.total);
+    hipStream_t st = as_stream(stream);
+    int rc = tgtc_sample_coarse(rays_o, rays_d, R, n_coarse, near_, far_, jitter, nullptr, ws.ts_c, stream);
+    if (rc) return rc;
+    float* rgb_c = rgb_coarse ? ws.rgb_c : nullptr;
+    if (rgb_c)
+        rc = styled_forward_rays_impl(coarse, style, rays_o, rays_d, ws.ts_c, z, R, n_coarse, rgb_c, ws.sigma_c, st);
+    else
+        rc = nerf_forward_rays_impl(coarse, rays_o, rays_d, ws.ts_c, R, n_coarse, nullptr, ws.sigma_c, st);
+    if (rc) return rc;
+    rc = launch_composite(rgb_c, ws.sigma_c, ws.ts_c, R, n_coarse, rgb_coarse, t_coarse, ws.w_c, st);
+    if (rc) return rc;
+    rc = launch_sample_fine(rays_o, rays_d, ws.ts_c, ws.w_c, R, n_coarse, n_fine, nullptr, ws.ts_f, st);
+    if (rc) return rc;
+    rc = styled_forward_rays_impl(fine, style, rays_o, rays_d, ws.ts_f, z, R, n_coarse + n_fine, ws.rgb_f, ws.sigma_f, st);
     if (rc) return rc;
     return launch_composite(ws.rgb_f, ws.sigma_f, ws.ts_f, R, n_coarse + n_fine, rgb_fine, t_fine, nullptr, st);
 }

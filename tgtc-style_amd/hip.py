@@ -53,7 +53,6 @@ _SIGNATURES = {
                              c_void_p, c_void_p],
 }
 _RESTYPES = {"tgtc_last_error": ctypes.c_char_p, "tgtc_render_workspace_bytes": c_size_t}
-# declared in the header but implemented by later milestones; bound when present
 _OPTIONAL = {
     "tgtc_style_create": [ctypes.POINTER(Linear), c_int, ctypes.POINTER(Linear), c_int, c_int, ctypes.POINTER(c_void_p)],
     "tgtc_concat_mlp_forward": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
@@ -162,5 +161,29 @@ def nerf_create(state, precision="fp16x3", prefix="net."):
     arr, keep = make_linears(pairs)
     h = c_void_p()
     check(lib.tgtc_nerf_create(arr, len(pairs), PRECISIONS[precision], ctypes.byref(h)))
+    del keep
+    return Net(h, precision)
+
+
+def style_create(concat_state=None, style_state=None, precision="fp16x3"):
+    """Pack StyleMLP_before_concat (5 linears `layers.0..4`) and / or StyleMLP_Wild_multilayers (8 linears
+    `layers.0..7`) state dicts into one device-resident handle.  A missing net is packed as zeros."""
+    require_gpu()
+    lib = load()
+    keep = []
+    if concat_state is not None:
+        ca, k = make_linears([(concat_state["layers.%d.weight" % i], concat_state["layers.%d.bias" % i]) for i in range(5)])
+        keep.append(k)
+        nc = 5
+    else:
+        ca, nc = None, 0
+    if style_state is not None:
+        sa, k = make_linears([(style_state["layers.%d.weight" % i], style_state["layers.%d.bias" % i]) for i in range(8)])
+        keep.append(k)
+        ns = 8
+    else:
+        sa, ns = None, 0
+    h = c_void_p()
+    check(lib.tgtc_style_create(ca, nc, sa, ns, PRECISIONS[precision], ctypes.byref(h)))
     del keep
     return Net(h, precision)

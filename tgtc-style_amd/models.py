@@ -151,6 +151,93 @@ class StyleNerf(nn.Module):
                             ('dirs', de.reshape(*lead, self.embedder_dir.out_dim))])
 
 
+class StyleMLP_before_concat(_Packed):
+    """reference models.py:120-147: 5 linears (the constructor loop breaks at the skip), every layer on
+    cat(h, latent) and the last additionally on x."""
+
+    def __init__(self, args):
+        super().__init__()
+        pe = args.embed_freq_coor * 3 * 2 + 3
+        if args.style_D != 8 or args.netwidth != 256 or pe != 63 or args.vae_latent != 32:
+            raise NotImplementedError("HIP kernels implement style_D=8, netwidth=256, embed_freq_coor=10, vae_latent=32")
+        self.skips = [4]
+        dims, dim = [], pe + args.vae_latent
+        for i in range(args.style_D - 1):
+            if i in self.skips:
+                dims.append(dim + pe)
+                break
+            dims.append(dim)
+            dim = args.netwidth + args.vae_latent
+        self.layers = nn.ModuleList([nn.Linear(d, args.netwidth) for d in dims])
+        self.precision = getattr(args, 'precision', 'fp16x3')
+
+    def _pack(self):
+        return hip.style_create(concat_state=self.state_dict(), precision=self.precision)
+
+    def forward(self, **kwargs):
+        x, latent = kwargs['x'], kwargs['latent']
+        hip.require_gpu(x, latent)
+        lib = hip.load()
+        lead = x.shape[:-1]
+        xf = x.reshape(-1, 63).to(torch.float32).contiguous()
+        lf = latent.expand(*lead, 32).reshape(-1, 32).to(torch.float32).contiguous()
+        out = torch.empty(xf.shape[0], 256, device=xf.device, dtype=torch.float32)
+        hip.check(lib.tgtc_concat_mlp_forward(self._packed().handle, hip.ptr(xf), hip.ptr(lf), xf.shape[0],
+                                              hip.ptr(out), hip.stream()))
+        return {'concat_features': out.reshape(*lead, 256)}
+
+
+class StyleMLP_Wild_multilayers(_Packed):
+    """reference models.py:149-180: 7 hidden linears + a 3-wide sigmoid head."""
+
+    def __init__(self, args):
+        super().__init__()
+        pe = args.embed_freq_coor * 3 * 2 + 3
+        if args.style_D != 8 or args.netwidth != 256 or pe != 63 or args.vae_latent != 32:
+            raise NotImplementedError("HIP kernels implement style_D=8, netwidth=256, embed_freq_coor=10, vae_latent=32")
+        self.skips = [4]
+        dims, dim = [], pe + 512 + args.vae_latent
+        for i in range(args.style_D - 1):
+            if i in self.skips:
+                dim += pe
+            dims.append(dim)
+            dim = args.netwidth + args.vae_latent
+        self.layers = nn.ModuleList([nn.Linear(d, args.netwidth) for d in dims] +
+                                    [nn.Linear(args.netwidth + args.vae_latent, 3)])
+        self.precision = getattr(args, 'precision', 'fp16x3')
+
+    def _pack(self):
+        return hip.style_create(style_state=self.state_dict(), precision=self.precision)
+
+    def forward(self, **kwargs):
+        x, conc, latent = kwargs['x'], kwargs['concated'], kwargs['latent']
+        hip.require_gpu(x, conc, latent)
+        lib = hip.load()
+        lead = x.shape[:-1]
+        xf = x.reshape(-1, 63).to(torch.float32).contiguous()
+        cf = conc.reshape(-1, 512).to(torch.float32).contiguous()
+        lf = latent.expand(*lead, 32).reshape(-1, 32).to(torch.float32).contiguous()
+        out = torch.empty(xf.shape[0], 3, device=xf.device, dtype=torch.float32)
+        hip.check(lib.tgtc_style_mlp_forward(self._packed().handle, hip.ptr(xf), hip.ptr(cf), hip.ptr(lf),
+                                             xf.shape[0], hip.ptr(out), hip.stream()))
+        return {'rgb': out.reshape(*lead, 3)}
+
+
+class StylePair(_Packed):
+    """The two style MLPs packed into ONE handle for the fused stylised kernel (rendering.RayRenderer)."""
+
+    def __init__(self, concat_model, style_model, precision=None):
+        super().__init__()
+        self.concat_model, self.style_model = concat_model, style_model
+        self.precision = precision or concat_model.precision
+
+    def _pack(self):
+        return hip.style_create(self.concat_model.state_dict(), self.style_model.state_dict(), self.precision)
+
+    def packed(self):
+        return self._packed()
+
+
 class StyleLatents_variational(nn.Module):
     """reference models.py:475-506."""
 
