@@ -1,0 +1,913 @@
+// 2-D style pass: patch embedding, the style transformer, the CNN decoder,
+// the VGG-19 prefix, calc_mean_std / AdaIN and the trans_test.py post-processing.
+//
+// One MFMA GEMM kernel does all the heavy lifting: C = act(alpha * A * B^T + bias [+ residual]) on
+// 128x128x32 workgroup tiles (4 waves, each a 64x64 sub-tile of 4x4 v_mfma_f32_16x16x32_f16 accumulators),
+// operands staged global -> registers -> LDS as fp16 hi (+ lo) halves.  The A operand comes through a
+// "row loader", which makes the same kernel a dense linear layer, a batched attention product, an 8x8
+// patch embedding or a 3x3 convolution with reflection padding and nearest x2 upsampling folded into
+// the gather (implicit GEMM over token-major / NHWC feature maps: a k-step is 32 consecutive channels of
+// one tap, i.e. one 128-byte line per row).
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/tgtc_style2d.h"
+#include "common.h"
+#include "mlp_core.h"
+
+namespace tgtc {
+
+constexpr int BM = 128, BN = 128, BK = 32, LDK = 40;  // LDK: 32 halves + 8 pad -> 80-byte rows, conflict-free b128 reads
+
+// ------------------------------------------------------------------------------------------------ row loaders
+// load4(ctx, k, v): v[j] = A(row, k + j), zero outside the matrix.  k is a multiple of 4.
+struct DenseRows {  // A(m,k) = p[m*ld + k]
+    const float* p;
+    long long ld, batch_stride;
+    int rows, K;
+    struct Ctx { const float* row; };
+    __device__ Ctx prep(int m) const { return Ctx{m < rows ? p + (long long)m * ld : nullptr}; }
+    __device__ void load4(const Ctx& c, int k, float (&v)[4]) const {
+        if (c.row && k + 3 < K && ((reinterpret_cast<size_t>(c.row + k) & 15) == 0)) {
+            const float4 t = *reinterpret_cast<const float4*>(c.row + k);
+            v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (c.row && k + j < K) ? c.row[k + j] : 0.0f;
+        }
+    }
+};
+
+__device__ __forceinline__ int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+struct ConvNHWC {  // 3x3, stride 1, ReflectionPad(1); input token-major [Hs*Ws, C]; optional nearest x2 upsample first
+    const float* p;
+    long long batch_stride;
+    int H, W, Hs, Ws, C, logC, up, rows, K;  // H,W: logical (post-upsample) = output size; k = tap*C + c
+    struct Ctx { int y, x; };
+    __device__ Ctx prep(int m) const { return m < rows ? Ctx{m / W, m % W} : Ctx{-1, 0}; }
+    __device__ void load4(const Ctx& c, int k, float (&v)[4]) const {
+        if (c.y < 0 || k >= K) {
+            v[0] = v[1] = v[2] = v[3] = 0.0f;
+            return;
+        }
+        const int tap = k >> logC, ch = k & (C - 1);
+        int sy = reflect(c.y + tap / 3 - 1, H), sx = reflect(c.x + tap % 3 - 1, W);
+        if (up) sy >>= 1, sx >>= 1;
+        const float4 t = *reinterpret_cast<const float4*>(p + (((long long)sy * Ws + sx) << logC) + ch);
+        v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+    }
+};
+
+struct ConvSmall {  // ksize x ksize (1 or 3), few input channels, arbitrary input strides; k = tap*C + c
+    const float* p;
+    long long batch_stride, s_pix, s_ch;
+    int H, W, C, ksize, rows, K;
+    struct Ctx { int y, x; };
+    __device__ Ctx prep(int m) const { return m < rows ? Ctx{m / W, m % W} : Ctx{-1, 0}; }
+    __device__ void load4(const Ctx& c, int k, float (&v)[4]) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kk = k + j;
+            float val = 0.0f;
+            if (c.y >= 0 && kk < K) {
+                const int tap = kk / C, ch = kk % C;
+                int sy = c.y, sx = c.x;
+                if (ksize == 3) sy = reflect(c.y + tap / 3 - 1, H), sx = reflect(c.x + tap % 3 - 1, W);
+                val = p[((long long)sy * W + sx) * s_pix + ch * s_ch];
+            }
+            v[j] = val;
+        }
+    }
+};
+
+struct PatchRows {  // 8x8 stride-8 patches of an NCHW image [3,H,W]; k = c*64 + dy*8 + dx (Conv2d weight order)
+    const float* p;
+    long long batch_stride;
+    int H, W, wt, rows, K;  // wt = W/8 tokens per row
+    struct Ctx { int py, px; };
+    __device__ Ctx prep(int m) const { return m < rows ? Ctx{m / wt, m % wt} : Ctx{-1, 0}; }
+    __device__ void load4(const Ctx& c, int k, float (&v)[4]) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kk = k + j;
+            float val = 0.0f;
+            if (c.py >= 0 && kk < K) {
+                const int ch = kk >> 6, dy = (kk >> 3) & 7, dx = kk & 7;
+                val = p[((long long)ch * H + (8 * c.py + dy)) * W + 8 * c.px + dx];
+            }
+            v[j] = val;
+        }
+    }
+};
+
+struct GemmOut {
+    float* C;
+    long long sm, sn, batch_stride;  // C[m*sm + n*sn]
+    const float* bias;               // [N] or null
+    const float* res;                // same layout as C, or null
+    float alpha;
+    int relu;
+};
+
+template <bool SPLIT>
+__device__ __forceinline__ void put4(half_t* hi, half_t* lo, const float (&v)[4]) {
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    half4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = (half_t)v[j];
+        l[j] = (half_t)(v[j] - (float)h[j]);
+    }
+    *reinterpret_cast<half4*>(hi) = h;
+    if constexpr (SPLIT) *reinterpret_cast<half4*>(lo) = l;
+}
+
+// B operand: either rows of W [N][K] (nn.Linear / conv weights, BL = DenseRows) or, with B_KMAJOR, a
+// k-major matrix B[k][n] = p[k*ld + n] (the V operand of attention).
+template <class AL, bool SPLIT, bool B_KMAJOR>
+__global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut out, int M, int N, int K) {
+    constexpr int NP = SPLIT ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) half_t sA[NP][BM][LDK];
+    __shared__ __attribute__((aligned(16))) half_t sB[NP][BN][LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, n16 = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    al.p += (long long)blockIdx.z * al.batch_stride;
+    bl.p += (long long)blockIdx.z * bl.batch_stride;
+    out.C += (long long)blockIdx.z * out.batch_stride;
+    if (out.res) out.res += (long long)blockIdx.z * out.batch_stride;
+
+    // staging map: 4 rows x one k-quad per thread
+    const int srow = tid >> 3, skq = (tid & 7) * 4;
+    typename AL::Ctx actx[4];
+    DenseRows::Ctx bctx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        actx[i] = al.prep(m0 + srow + 32 * i);
+        if constexpr (!B_KMAJOR) bctx[i] = bl.prep(n0 + srow + 32 * i);
+    }
+    // k-major B: thread covers k = (tid>>5) + 8i, n-quad (tid&31)*4
+    const int bk = tid >> 5, bnq = (tid & 31) * 4;
+
+    float ra[4][4], rb[4][4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            al.load4(actx[i], k0 + skq, ra[i]);
+            if constexpr (!B_KMAJOR) {
+                bl.load4(bctx[i], k0 + skq, rb[i]);
+            } else {
+                const int k = k0 + bk + 8 * i;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    rb[i][j] = (k < K && n0 + bnq + j < N) ? bl.p[(long long)k * bl.ld + n0 + bnq + j] : 0.0f;
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            put4<SPLIT>(&sA[0][srow + 32 * i][skq], &sA[NP - 1][srow + 32 * i][skq], ra[i]);
+            if constexpr (!B_KMAJOR) {
+                put4<SPLIT>(&sB[0][srow + 32 * i][skq], &sB[NP - 1][srow + 32 * i][skq], rb[i]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const half_t h = (half_t)rb[i][j];
+                    sB[0][bnq + j][bk + 8 * i] = h;
+                    if constexpr (SPLIT) sB[1][bnq + j][bk + 8 * i] = (half_t)(rb[i][j] - (float)h);
+                }
+            }
+        }
+    };
+
+    float4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    const int KT = (K + BK - 1) / BK;
+    fetch(0);
+    for (int kt = 0; kt < KT; ++kt) {
+        stash();
+        __syncthreads();
+        if (kt + 1 < KT) fetch((kt + 1) * BK);
+        half8 ah[4], al_[4], bh[4], bl_[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = *reinterpret_cast<const half8*>(&sA[0][64 * wm + 16 * i + n16][8 * g]);
+            bh[i] = *reinterpret_cast<const half8*>(&sB[0][64 * wn + 16 * i + n16][8 * g]);
+            if constexpr (SPLIT) {
+                al_[i] = *reinterpret_cast<const half8*>(&sA[1][64 * wm + 16 * i + n16][8 * g]);
+                bl_[i] = *reinterpret_cast<const half8*>(&sB[1][64 * wn + 16 * i + n16][8 * g]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = mfma16(ah[i], bh[j], acc[i][j]);
+                if constexpr (SPLIT) {
+                    acc[i][j] = mfma16(al_[i], bh[j], acc[i][j]);
+                    acc[i][j] = mfma16(ah[i], bl_[j], acc[i][j]);
+                }
+            }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds rows m = .. + 4g + r, column n = .. + (lane & 15)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 64 * wn + 16 * j + n16;
+            if (n >= N) continue;
+            const float b = out.bias ? out.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 64 * wm + 16 * i + 4 * g + r;
+                if (m >= M) continue;
+                const long long o = (long long)m * out.sm + (long long)n * out.sn;
+                float v = out.alpha * acc[i][j][r] + b;
+                if (out.res) v += out.res[o];
+                if (out.relu) v = fmaxf(v, 0.0f);
+                out.C[o] = v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ small kernels
+// out[row] = LayerNorm(a[row] + b[row]) * w + bias over 512 features; one wavefront per row (eps 1e-5)
+__global__ void __launch_bounds__(256) layernorm512_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ out, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float v[8], s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j;
+        v[j] = a[(long long)row * 512 + c] + (b ? b[(long long)row * 512 + c] : 0.0f);
+        s += v[j];
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s * (1.0f / 512.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q += (v[j] - mean) * (v[j] - mean);
+#pragma unroll
+    for (int off = 32; off; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 512.0f) + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lane + 64 * j;
+        out[(long long)row * 512 + c] = (v[j] - mean) * rstd * w[c] + bias[c];
+    }
+}
+
+// in-place softmax over rows of length S; one workgroup per row
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ x, int S) {
+    __shared__ float red[4];
+    float* row = x + (long long)blockIdx.x * S;
+    const int tid = threadIdx.x;
+    float mx = -INFINITY;
+    for (int i = tid; i < S; i += 256) mx = fmaxf(mx, row[i]);
+#pragma unroll
+    for (int off = 32; off; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int i = tid; i < S; i += 256) {
+        const float e = expf(row[i] - mx);
+        row[i] = e;
+        s += e;
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int i = tid; i < S; i += 256) row[i] *= inv;
+}
+
+__global__ void __launch_bounds__(256) add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
+// MaxPool2d(2,2,ceil_mode=True) on token-major [H*W, C]
+__global__ void __launch_bounds__(256) maxpool2_kernel(const float* __restrict__ in, int H, int W, int C,
+                                                       float* __restrict__ out) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)Ho * Wo * C) return;
+    const int c = (int)(i % C);
+    const int p = (int)(i / C), y = p / Wo, x = p % Wo;
+    float m = -INFINITY;
+    for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+            const int sy = 2 * y + dy, sx = 2 * x + dx;
+            if (sy < H && sx < W) m = fmaxf(m, in[((long long)sy * W + sx) * C + c]);
+        }
+    out[i] = m;
+}
+
+// [n, C] -> [C, n] (to_nchw) or back
+__global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ in, int rows, int cols,
+                                                        float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (by + j < rows && bx + tx < cols) tile[j][tx] = in[(long long)(by + j) * cols + bx + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (bx + j < cols && by + tx < rows) out[(long long)(bx + j) * rows + by + tx] = tile[tx][j];
+}
+
+// per-channel mean and sqrt(unbiased var + eps) over HW; one workgroup per channel (function.py:4-12)
+__global__ void __launch_bounds__(256) mean_std_kernel(const float* __restrict__ feat, long long HW, float eps,
+                                                       float* __restrict__ mean, float* __restrict__ std_) {
+    __shared__ double red[2][4];
+    const float* row = feat + (long long)blockIdx.x * HW;
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < HW; i += 256) s += row[i];
+#pragma unroll
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s;
+    __syncthreads();
+    const double mu = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (double)HW;
+    double q = 0.0;
+    for (long long i = threadIdx.x; i < HW; i += 256) {
+        const double d = row[i] - mu;
+        q += d * d;
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) q += __shfl_xor(q, off);
+    if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double var = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (double)(HW - 1);
+        mean[blockIdx.x] = (float)mu;
+        std_[blockIdx.x] = sqrtf((float)var + eps);
+    }
+}
+
+__global__ void __launch_bounds__(256) adain_kernel(const float* __restrict__ content, long long HW, int C,
+                                                    const float* __restrict__ st, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW * C) return;
+    const int c = (int)(i / HW);
+    // st: [cm | cs | sm | ss], each C
+    out[i] = (content[i] - st[c]) / st[C + c] * st[3 * C + c] + st[2 * C + c];
+}
+
+// nn.Upsample(mode='bilinear', align_corners=True)
+__global__ void __launch_bounds__(256) resize_bilinear_kernel(const float* __restrict__ in, int C, int h, int w,
+                                                              float* __restrict__ out, int H, int W) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)C * H * W) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H), c = (int)(i / ((long long)W * H));
+    const float ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, rx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const float fy = ry * y, fx = rx * x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
+    const float ly = fy - y0, lx = fx - x0;
+    const float* p = in + (long long)c * h * w;
+    out[i] = (1.f - ly) * ((1.f - lx) * p[y0 * w + x0] + lx * p[y0 * w + x1]) +
+             ly * ((1.f - lx) * p[y1 * w + x0] + lx * p[y1 * w + x1]);
+}
+
+// trans_test.py:176.  hs token-major [n,512]; flat (c,p) order index f = r*512 + j -> c = f / n, p = f % n.
+// One workgroup per output column j; float64 accumulation.
+__global__ void __launch_bounds__(256) style_feature_kernel(const float* __restrict__ hs, int n,
+                                                            float* __restrict__ feature) {
+    __shared__ double red[2][4];
+    const int j = blockIdx.x;
+    double s = 0.0;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        const long long f = (long long)r * 512 + j;
+        s += hs[(f % n) * 512 + f / n];
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s;
+    __syncthreads();
+    const double mu = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / n;
+    double q = 0.0;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        const long long f = (long long)r * 512 + j;
+        const double d = hs[(f % n) * 512 + f / n] - mu;
+        q += d * d;
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) q += __shfl_xor(q, off);
+    if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        feature[j] = (float)mu;
+        feature[512 + j] = (float)((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (n - 1));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct Bump {  // workspace carving
+    char* base;
+    size_t off, cap;
+    bool ok = true;
+    float* take(size_t floats) {
+        const size_t bytes = (floats * sizeof(float) + 255) & ~(size_t)255;
+        if (off + bytes > cap) {
+            ok = false;
+            return reinterpret_cast<float*>(base);
+        }
+        float* p = reinterpret_cast<float*>(base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+}  // namespace tgtc
+
+using namespace tgtc;
+
+struct tgtc_style2d {
+    int precision;
+    std::vector<float*> allocs;
+    std::map<std::string, const float*> tr, emb, dec, vgg;  // device pointers by reference key name
+};
+
+namespace tgtc {
+
+template <class AL, bool KM>
+static int launch_gemm(const tgtc_style2d* h, AL al, DenseRows bl, GemmOut out, int M, int N, int K, int batch,
+                       hipStream_t st) {
+    if (M <= 0 || N <= 0) return TGTC_OK;
+    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, batch);
+    if (h->precision == TGTC_PREC_FP16)
+        gemm_kernel<AL, false, KM><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+    else
+        gemm_kernel<AL, true, KM><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
+}
+
+// y[M,N] (ld ldy) = act(x[M,K] (ld ldx) * W[N,K]^T + b)
+static int linear(const tgtc_style2d* h, const float* x, long long ldx, int M, int K, const float* W, const float* b,
+                  int N, float* y, long long ldy, const float* res, int relu, hipStream_t st) {
+    DenseRows al{x, ldx, 0, M, K}, bl{W, K, 0, N, K};
+    GemmOut out{y, ldy, 1, 0, b, res, 1.0f, relu};
+    return launch_gemm<DenseRows, false>(h, al, bl, out, M, N, K, 1, st);
+}
+
+static int layernorm(const float* a, const float* b, const float* w, const float* bias, float* out, int rows,
+                     hipStream_t st) {
+    layernorm512_kernel<<<(rows + 3) / 4, 256, 0, st>>>(a, b, w, bias, out, rows);
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
+}
+
+static const float* need(const std::map<std::string, const float*>& m, const std::string& k) {
+    auto it = m.find(k);
+    return it == m.end() ? nullptr : it->second;
+}
+
+#define TGTC_TRY(expr)          \
+    do {                        \
+        int rc__ = (expr);      \
+        if (rc__) return rc__;  \
+    } while (0)
+
+// nn.MultiheadAttention forward (batch 1): q_in [L,512] ld ldq, k_in / v_in [S,512] -> out [L,512]
+static int mha(const tgtc_style2d* h, const std::string& p, const float* q_in, long long ldq, int L, const float* k_in,
+               long long ldk, const float* v_in, long long ldv, int S, Bump& ws, float* out, hipStream_t st) {
+    const float* w = need(h->tr, p + "in_proj_weight");
+    const float* b = need(h->tr, p + "in_proj_bias");
+    const float* ow = need(h->tr, p + "out_proj.weight");
+    const float* ob = need(h->tr, p + "out_proj.bias");
+    if (!w || !b || !ow || !ob) return fail(TGTC_ERR_ARG, "style2d: missing attention parameters '%s*'", p.c_str());
+    float* Q = ws.take((size_t)L * 512);
+    float* Kp = ws.take((size_t)S * 512);
+    float* V = ws.take((size_t)S * 512);
+    float* O = ws.take((size_t)L * 512);
+    float* P = ws.take((size_t)8 * L * S);
+    if (!ws.ok) return fail(TGTC_ERR_ARG, "style2d: workspace too small for attention (L=%d, S=%d)", L, S);
+    TGTC_TRY(linear(h, q_in, ldq, L, 512, w, b, 512, Q, 512, nullptr, 0, st));
+    TGTC_TRY(linear(h, k_in, ldk, S, 512, w + 512 * 512, b + 512, 512, Kp, 512, nullptr, 0, st));
+    TGTC_TRY(linear(h, v_in, ldv, S, 512, w + 2 * 512 * 512, b + 1024, 512, V, 512, nullptr, 0, st));
+    {   // scores[h] = (q_h / sqrt(64)) k_h^T   (the 1/8 scale is exact in binary, so scaling the product == scaling q)
+        DenseRows al{Q, 512, 64, L, 64}, bl{Kp, 512, 64, S, 64};
+        GemmOut o{P, S, 1, (long long)L * S, nullptr, nullptr, 0.125f, 0};
+        TGTC_TRY((launch_gemm<DenseRows, false>(h, al, bl, o, L, S, 64, 8, st)));
+    }
+    softmax_rows_kernel<<<8 * L, 256, 0, st>>>(P, S);
+    TGTC_LAUNCH_CHECK();
+    {   // O[:, 64h:64h+64] = P_h V_h
+        DenseRows al{P, S, (long long)L * S, L, S}, bl{V, 512, 64, 64, S};
+        GemmOut o{O, 512, 1, 64, nullptr, nullptr, 1.0f, 0};
+        TGTC_TRY((launch_gemm<DenseRows, true>(h, al, bl, o, L, 64, S, 8, st)));
+    }
+    return linear(h, O, 512, L, 512, ow, ob, 512, out, 512, nullptr, 0, st);
+}
+
+static int ffn_norm(const tgtc_style2d* h, const std::string& p, const std::string& norm, const float* x, int rows,
+                    Bump& ws, float* out, hipStream_t st) {
+    const float *w1 = need(h->tr, p + "linear1.weight"), *b1 = need(h->tr, p + "linear1.bias");
+    const float *w2 = need(h->tr, p + "linear2.weight"), *b2 = need(h->tr, p + "linear2.bias");
+    const float *nw = need(h->tr, p + norm + ".weight"), *nb = need(h->tr, p + norm + ".bias");
+    if (!w1 || !b1 || !w2 || !b2 || !nw || !nb) return fail(TGTC_ERR_ARG, "style2d: missing FFN parameters '%s*'", p.c_str());
+    float* hid = ws.take((size_t)rows * 2048);
+    float* y = ws.take((size_t)rows * 512);
+    if (!ws.ok) return fail(TGTC_ERR_ARG, "style2d: workspace too small for the feed-forward block");
+    TGTC_TRY(linear(h, x, 512, rows, 512, w1, b1, 2048, hid, 2048, nullptr, 1, st));
+    TGTC_TRY(linear(h, hid, 2048, rows, 2048, w2, b2, 512, y, 512, nullptr, 0, st));
+    return layernorm(x, y, nw, nb, out, rows, st);
+}
+
+// transformer.py:167-184
+static int encoder_layer(const tgtc_style2d* h, const std::string& p, const float* src, int S, bool has_pos, Bump ws,
+                         float* out, hipStream_t st) {
+    const float* n1w = need(h->tr, p + "norm1.weight");
+    const float* n1b = need(h->tr, p + "norm1.bias");
+    if (!n1w || !n1b) return fail(TGTC_ERR_ARG, "style2d: missing '%snorm1.*'", p.c_str());
+    const int width = has_pos ? 1024 : 1536;
+    const float* pw = need(h->tr, p + (has_pos ? "qk.weight" : "qkv.weight"));
+    if (!pw) return fail(TGTC_ERR_ARG, "style2d: missing '%sqk(v).weight'", p.c_str());
+    float* proj = ws.take((size_t)S * width);
+    float* attn = ws.take((size_t)S * 512);
+    float* x1 = ws.take((size_t)S * 512);
+    if (!ws.ok) return fail(TGTC_ERR_ARG, "style2d: workspace too small for an encoder layer (S=%d)", S);
+    TGTC_TRY(linear(h, src, 512, S, 512, pw, nullptr, width, proj, width, nullptr, 0, st));
+    // without pos the value AND the residual are the third chunk of the projection (transformer.py:173-174)
+    const float* val = has_pos ? src : proj + 1024;
+    const long long ldv = has_pos ? 512 : width;
+    TGTC_TRY(mha(h, p + "self_attn.", proj, width, S, proj + 512, width, val, ldv, S, ws, attn, st));
+    if (has_pos) {
+        TGTC_TRY(layernorm(src, attn, n1w, n1b, x1, S, st));
+    } else {
+        // residual operand is strided (ld 1536): fold the add into a dense copy first
+        float* tmp = ws.take((size_t)S * 512);
+        if (!ws.ok) return fail(TGTC_ERR_ARG, "style2d: workspace too small for an encoder layer (S=%d)", S);
+        TGTC_HIP_CHECK(hipMemcpy2DAsync(tmp, 512 * sizeof(float), val, width * sizeof(float), 512 * sizeof(float), S,
+                                        hipMemcpyDeviceToDevice, st));
+        TGTC_TRY(layernorm(tmp, attn, n1w, n1b, x1, S, st));
+    }
+    return ffn_norm(h, p, "norm2", x1, S, ws, out, st);
+}
+
+// transformer.py:236-263 with pos = None
+static int decoder_layer(const tgtc_style2d* h, const std::string& p, const float* tgt, int L, const float* memory,
+                         int S, const float* qpos, Bump ws, float* out, hipStream_t st) {
+    const float *n1w = need(h->tr, p + "norm1.weight"), *n1b = need(h->tr, p + "norm1.bias");
+    const float *n2w = need(h->tr, p + "norm2.weight"), *n2b = need(h->tr, p + "norm2.bias");
+    if (!n1w || !n1b || !n2w || !n2b) return fail(TGTC_ERR_ARG, "style2d: missing '%snorm*'", p.c_str());
+    float* q = ws.take((size_t)L * 512);
+    float* a = ws.take((size_t)L * 512);
+    float* t1 = ws.take((size_t)L * 512);
+    float* t2 = ws.take((size_t)L * 512);
+    if (!ws.ok) return fail(TGTC_ERR_ARG, "style2d: workspace too small for a decoder layer (L=%d)", L);
+    const long long n = (long long)L * 512;
+    add_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(tgt, qpos, q, n);
+    TGTC_LAUNCH_CHECK();
+    {
+        Bump inner = ws;
+        TGTC_TRY(mha(h, p + "self_attn.", q, 512, L, memory, 512, memory, 512, S, inner, a, st));
+    }
+    TGTC_TRY(layernorm(tgt, a, n1w, n1b, t1, L, st));
+    add_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(t1, qpos, q, n);
+    TGTC_LAUNCH_CHECK();
+    {
+        Bump inner = ws;
+        TGTC_TRY(mha(h, p + "multihead_attn.", q, 512, L, memory, 512, memory, 512, S, inner, a, st));
+    }
+    TGTC_TRY(layernorm(t1, a, n2w, n2b, t2, L, st));
+    return ffn_norm(h, p, "norm3", t2, L, ws, out, st);
+}
+
+static size_t layer_ws_floats(size_t L, size_t S) {
+    // generous upper bound for one encoder / decoder layer incl. attention scratch (256-byte rounding included)
+    return 1536 * S + 12 * 512 * (L + S) + 8 * L * S + 2048 * (L + S) + 64 * 64;
+}
+
+static int conv3x3(const tgtc_style2d* h, const float* w, const float* b, const float* in, int Hs, int Ws, int up,
+                   int Cin, int Cout, int relu, float* out, long long sm, long long sn, hipStream_t st) {
+    int logC = 0;
+    while ((1 << logC) < Cin) ++logC;
+    if ((1 << logC) != Cin || Cin < 4) return fail(TGTC_ERR_UNSUPPORTED, "conv3x3: C_in=%d must be a power of two >= 4", Cin);
+    const int H = up ? 2 * Hs : Hs, W = up ? 2 * Ws : Ws, M = H * W, K = 9 * Cin;
+    ConvNHWC al{in, 0, H, W, Hs, Ws, Cin, logC, up, M, K};
+    DenseRows bl{w, K, 0, Cout, K};
+    GemmOut o{out, sm, sn, 0, b, nullptr, 1.0f, relu};
+    return launch_gemm<ConvNHWC, false>(h, al, bl, o, M, Cout, K, 1, st);
+}
+
+}  // namespace tgtc
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static int upload_group(tgtc_style2d* h, const tgtc_named_tensor* t, int n, std::map<std::string, const float*>& dst,
+                        bool repack_conv3) {
+    if (!t || n <= 0) return TGTC_OK;
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!t[i].name || !t[i].data || t[i].numel <= 0) return fail(TGTC_ERR_ARG, "style2d_create: bad tensor #%d", i);
+        total += ((size_t)t[i].numel + 63) & ~(size_t)63;
+    }
+    std::vector<float> host(total, 0.0f);
+    std::vector<size_t> offs(n);
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        offs[i] = off;
+        const std::string name = t[i].name;
+        const bool is_w = name.size() > 7 && name.compare(name.size() - 7, 7, ".weight") == 0;
+        // 3x3 conv weights [N][C][3][3] -> [N][tap][C] (k = tap*C + c, the implicit-GEMM k order)
+        if (repack_conv3 && is_w && t[i].numel % 9 == 0 && name != "0.weight") {
+            // identify (N, C): conv weights of the decoder / vgg are [N][C][3][3] with known N from the bias
+            // tensor that follows; derive C from numel once N is known
+            long long N = -1;
+            const std::string bname = name.substr(0, name.size() - 7) + ".bias";
+            for (int j = 0; j < n; ++j)
+                if (bname == t[j].name) N = t[j].numel;
+            if (N <= 0 || t[i].numel % (9 * N)) return fail(TGTC_ERR_ARG, "style2d_create: cannot shape conv '%s'", t[i].name);
+            const long long C = t[i].numel / (9 * N);
+            for (long long nn = 0; nn < N; ++nn)
+                for (long long c = 0; c < C; ++c)
+                    for (int tap = 0; tap < 9; ++tap)
+                        host[off + (nn * 9 + tap) * C + c] = t[i].data[(nn * C + c) * 9 + tap];
+        } else {
+            std::memcpy(host.data() + off, t[i].data, (size_t)t[i].numel * sizeof(float));
+        }
+        off += ((size_t)t[i].numel + 63) & ~(size_t)63;
+    }
+    float* dev = nullptr;
+    TGTC_HIP_CHECK(hipMalloc((void**)&dev, total * sizeof(float)));
+    h->allocs.push_back(dev);
+    TGTC_HIP_CHECK(hipMemcpy(dev, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    for (int i = 0; i < n; ++i) dst[t[i].name] = dev + offs[i];
+    return TGTC_OK;
+}
+
+extern "C" int tgtc_s2d_create(const tgtc_named_tensor* transformer, int n_transformer,
+                               const tgtc_named_tensor* embedding, int n_embedding, const tgtc_named_tensor* decoder,
+                               int n_decoder, const tgtc_named_tensor* vgg, int n_vgg, int precision,
+                               tgtc_style2d** out) {
+    TGTC_REQUIRE(out, "style2d_create: null output");
+    TGTC_REQUIRE(precision == TGTC_PREC_FP16 || precision == TGTC_PREC_FP16X3, "style2d_create: unknown precision %d", precision);
+    tgtc_style2d* h = new tgtc_style2d();
+    h->precision = precision;
+    int rc = upload_group(h, transformer, n_transformer, h->tr, false);
+    if (!rc) rc = upload_group(h, embedding, n_embedding, h->emb, false);
+    if (!rc) rc = upload_group(h, decoder, n_decoder, h->dec, true);
+    if (!rc) rc = upload_group(h, vgg, n_vgg, h->vgg, true);
+    if (rc) {
+        tgtc_s2d_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return TGTC_OK;
+}
+
+extern "C" int tgtc_s2d_destroy(tgtc_style2d* h) {
+    if (!h) return TGTC_OK;
+    for (float* p : h->allocs) (void)hipFree(p);
+    delete h;
+    return TGTC_OK;
+}
+
+extern "C" int tgtc_s2d_patch_embed(const tgtc_style2d* h, const float* img, int H, int W, float* tokens,
+                                    void* stream) {
+    TGTC_REQUIRE(h && H >= 8 && W >= 8, "patch_embed: bad argument");
+    TGTC_REQUIRE(img && tokens, "patch_embed: null pointer");
+    const float *w = need(h->emb, "proj.weight"), *b = need(h->emb, "proj.bias");
+    if (!w || !b) return fail(TGTC_ERR_ARG, "patch_embed: embedding parameters were not given to tgtc_s2d_create");
+    const int ht = H / 8, wt = W / 8, M = ht * wt;
+    PatchRows al{img, 0, H, W, wt, M, 192};
+    DenseRows bl{w, 192, 0, 512, 192};
+    GemmOut o{tokens, 512, 1, 0, b, nullptr, 1.0f, 0};
+    return launch_gemm<PatchRows, false>(h, al, bl, o, M, 512, 192, 1, as_stream(stream));
+}
+
+extern "C" size_t tgtc_s2d_transformer_workspace_bytes(int ns, int nc) {
+    if (ns <= 0 || nc <= 0) return 0;
+    const size_t big = (size_t)(ns > nc ? ns : nc);
+    return (layer_ws_floats(big, big) + 4 * 512 * big) * sizeof(float);
+}
+
+extern "C" int tgtc_s2d_mha(const tgtc_style2d* h, const char* prefix, const float* query, int L, const float* key,
+                            const float* value, int S, void* workspace, size_t workspace_bytes, float* out,
+                            void* stream) {
+    TGTC_REQUIRE(h && prefix && L > 0 && S > 0 && query && key && value && workspace && out, "mha: bad argument");
+    Bump ws{static_cast<char*>(workspace), 0, workspace_bytes};
+    return mha(h, prefix, query, 512, L, key, 512, value, 512, S, ws, out, as_stream(stream));
+}
+
+extern "C" int tgtc_s2d_encoder_layer(const tgtc_style2d* h, const char* prefix, const float* src, int S, int has_pos,
+                                      void* workspace, size_t workspace_bytes, float* out, void* stream) {
+    TGTC_REQUIRE(h && prefix && S > 0 && src && workspace && out, "encoder_layer: bad argument");
+    Bump ws{static_cast<char*>(workspace), 0, workspace_bytes};
+    return encoder_layer(h, prefix, src, S, has_pos != 0, ws, out, as_stream(stream));
+}
+
+extern "C" int tgtc_s2d_decoder_layer(const tgtc_style2d* h, const char* prefix, const float* tgt, int L,
+                                      const float* memory, int S, const float* query_pos, void* workspace,
+                                      size_t workspace_bytes, float* out, void* stream) {
+    TGTC_REQUIRE(h && prefix && L > 0 && S > 0 && tgt && memory && query_pos && workspace && out, "decoder_layer: bad argument");
+    Bump ws{static_cast<char*>(workspace), 0, workspace_bytes};
+    return decoder_layer(h, prefix, tgt, L, memory, S, query_pos, ws, out, as_stream(stream));
+}
+
+extern "C" int tgtc_s2d_transformer_forward(const tgtc_style2d* h, const float* style_tokens, int ns,
+                                            const float* content_tokens, int nc, void* workspace,
+                                            size_t workspace_bytes, float* hs, void* stream) {
+    TGTC_REQUIRE(h && ns > 0 && nc > 0 && style_tokens && content_tokens && workspace && hs, "transformer_forward: bad argument");
+    TGTC_REQUIRE(workspace_bytes >= tgtc_s2d_transformer_workspace_bytes(ns, nc), "transformer_forward: workspace too small");
+    hipStream_t st = as_stream(stream);
+    Bump ws{static_cast<char*>(workspace), 0, workspace_bytes};
+    float* s[2] = {ws.take((size_t)ns * 512), ws.take((size_t)ns * 512)};
+    float* c[2] = {ws.take((size_t)nc * 512), ws.take((size_t)nc * 512)};
+    const float* cur = style_tokens;
+    for (int i = 0; i < 3; ++i) {  // transformer.py:62
+        TGTC_TRY(encoder_layer(h, "encoder_s.layers." + std::to_string(i) + ".", cur, ns, false, ws, s[i & 1], st));
+        cur = s[i & 1];
+    }
+    const float* style_enc = cur;
+    cur = content_tokens;
+    for (int i = 0; i < 3; ++i) {  // transformer.py:63 (pos = content embedding is only a switch, transformer.py:172-176)
+        TGTC_TRY(encoder_layer(h, "encoder_c.layers." + std::to_string(i) + ".", cur, nc, true, ws, c[i & 1], st));
+        cur = c[i & 1];
+    }
+    // decoder: tgt = encoded content, memory = encoded style, query_pos = content embedding (transformer.py:64-65)
+    const float* tgt = cur;             // c[0] after three layers
+    float* pp[2] = {c[1], c[0]};        // ping-pong; layer 0 reads c[0] writes c[1], layer 1 reads c[1] writes c[0], ...
+    for (int i = 0; i < 3; ++i) {
+        TGTC_TRY(decoder_layer(h, "decoder.layers." + std::to_string(i) + ".", tgt, nc, style_enc, ns, content_tokens,
+                               ws, pp[i & 1], st));
+        tgt = pp[i & 1];
+    }
+    const float *nw = need(h->tr, "decoder.norm.weight"), *nb = need(h->tr, "decoder.norm.bias");
+    if (!nw || !nb) return fail(TGTC_ERR_ARG, "transformer_forward: missing decoder.norm.*");
+    return layernorm(tgt, nullptr, nw, nb, hs, nc, st);  // transformer.py:131-132
+}
+
+// ---- CNN decoder (tctrans.py:36-66)
+extern "C" size_t tgtc_s2d_decode_workspace_bytes(int h, int w) {
+    if (h <= 0 || w <= 0) return 0;
+    // largest pair of live maps: [8h*8w, 64] twice
+    return 2 * ((size_t)64 * h * w * 64 * sizeof(float) + 256);
+}
+
+extern "C" int tgtc_s2d_cnn_decode(const tgtc_style2d* hd, const float* tokens, int h, int w, void* workspace,
+                                   size_t workspace_bytes, float* image, void* stream) {
+    TGTC_REQUIRE(hd && h > 0 && w > 0 && tokens && workspace && image, "cnn_decode: bad argument");
+    TGTC_REQUIRE(workspace_bytes >= tgtc_s2d_decode_workspace_bytes(h, w), "cnn_decode: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const size_t half = workspace_bytes / 2 & ~(size_t)255;
+    float* buf[2] = {static_cast<float*>(workspace), reinterpret_cast<float*>(static_cast<char*>(workspace) + half)};
+    struct L { int idx, cin, cout, relu, up_before; };
+    static const L layers[9] = {{1, 512, 256, 1, 0},  {5, 256, 256, 1, 1},  {8, 256, 256, 1, 0}, {11, 256, 256, 1, 0},
+                                {14, 256, 128, 1, 0}, {18, 128, 128, 1, 1}, {21, 128, 64, 1, 0}, {25, 64, 64, 1, 1},
+                                {28, 64, 3, 0, 0}};
+    const float* cur = tokens;
+    int Hs = h, Ws = w;
+    for (int i = 0; i < 9; ++i) {
+        const L& l = layers[i];
+        const float* wt = need(hd->dec, std::to_string(l.idx) + ".weight");
+        const float* bs = need(hd->dec, std::to_string(l.idx) + ".bias");
+        if (!wt || !bs) return fail(TGTC_ERR_ARG, "cnn_decode: decoder parameter %d.* missing", l.idx);
+        const int H = l.up_before ? 2 * Hs : Hs, W = l.up_before ? 2 * Ws : Ws;
+        const bool last = i == 8;
+        float* dst = last ? image : buf[i & 1];
+        // last conv writes NCHW [3, H*W]; the others token-major [H*W, C]
+        TGTC_TRY(conv3x3(hd, wt, bs, cur, Hs, Ws, l.up_before, l.cin, l.cout, l.relu, dst, last ? 1 : l.cout,
+                         last ? (long long)H * W : 1, st));
+        cur = dst, Hs = H, Ws = W;
+    }
+    return TGTC_OK;
+}
+
+// ---- VGG-19 prefix (tctrans.py:68-99, :161-166)
+extern "C" size_t tgtc_s2d_vgg_workspace_bytes(int H, int W) {
+    if (H <= 0 || W <= 0) return 0;
+    return 3 * ((size_t)H * W * 64 * sizeof(float) + 256);
+}
+
+extern "C" int tgtc_s2d_vgg_encode(const tgtc_style2d* h, const float* img, int H, int W, void* workspace,
+                                   size_t workspace_bytes, float* relu1_1, float* relu2_1, float* relu3_1,
+                                   float* relu4_1, void* stream) {
+    TGTC_REQUIRE(h && H > 0 && W > 0 && img && workspace, "vgg_encode: bad argument");
+    TGTC_REQUIRE(workspace_bytes >= tgtc_s2d_vgg_workspace_bytes(H, W), "vgg_encode: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const size_t third = workspace_bytes / 3 & ~(size_t)255;
+    float* buf[3];
+    for (int i = 0; i < 3; ++i) buf[i] = reinterpret_cast<float*>(static_cast<char*>(workspace) + i * third);
+    auto par = [&](int idx, const char* what) { return need(h->vgg, std::to_string(idx) + what); };
+    for (int idx : {0, 2, 5, 9, 12, 16, 19, 22, 25, 29})
+        if (!par(idx, ".weight") || !par(idx, ".bias")) return fail(TGTC_ERR_ARG, "vgg_encode: vgg parameter %d.* missing", idx);
+    const int HW = H * W;
+    {   // vgg.0: Conv2d(3,3,1x1) on the NCHW image -> NCHW scratch
+        ConvSmall al{img, 0, 1, HW, H, W, 3, 1, HW, 3};
+        DenseRows bl{par(0, ".weight"), 3, 0, 3, 3};
+        GemmOut o{buf[0], 1, HW, 0, par(0, ".bias"), nullptr, 1.0f, 0};
+        TGTC_TRY((launch_gemm<ConvSmall, false>(h, al, bl, o, HW, 3, 3, 1, st)));
+    }
+    {   // vgg.2: pad + Conv2d(3,64,3x3) + relu -> relu1_1, token-major [HW,64].
+        // The 3x3 weights of this layer were repacked to [N][tap][c] like every other 3x3 conv.
+        ConvSmall al{buf[0], 0, 1, HW, H, W, 3, 3, HW, 27};
+        DenseRows bl{par(2, ".weight"), 27, 0, 64, 27};
+        GemmOut o{buf[1], 64, 1, 0, par(2, ".bias"), nullptr, 1.0f, 1};
+        TGTC_TRY((launch_gemm<ConvSmall, false>(h, al, bl, o, HW, 64, 27, 1, st)));
+    }
+    auto emit = [&](const float* tok, int n, int C, float* dst) -> int {
+        if (!dst) return TGTC_OK;
+        dim3 grid((C + 31) / 32, (n + 31) / 32);
+        transpose_kernel<<<grid, 256, 0, st>>>(tok, n, C, dst);
+        TGTC_LAUNCH_CHECK();
+        return TGTC_OK;
+    };
+    auto pool = [&](const float* in, int Hh, int Ww, int C, float* out) -> int {
+        const long long n = (long long)((Hh + 1) / 2) * ((Ww + 1) / 2) * C;
+        maxpool2_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(in, Hh, Ww, C, out);
+        TGTC_LAUNCH_CHECK();
+        return TGTC_OK;
+    };
+    auto conv = [&](int idx, const float* in, int Hh, int Ww, int cin, int cout, float* out) -> int {
+        return conv3x3(h, par(idx, ".weight"), par(idx, ".bias"), in, Hh, Ww, 0, cin, cout, 1, out, cout, 1, st);
+    };
+    TGTC_TRY(emit(buf[1], HW, 64, relu1_1));
+    TGTC_TRY(conv(5, buf[1], H, W, 64, 64, buf[2]));                 // relu1_2
+    int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+    TGTC_TRY(pool(buf[2], H, W, 64, buf[0]));
+    TGTC_TRY(conv(9, buf[0], H2, W2, 64, 128, buf[1]));              // relu2_1
+    TGTC_TRY(emit(buf[1], H2 * W2, 128, relu2_1));
+    TGTC_TRY(conv(12, buf[1], H2, W2, 128, 128, buf[2]));            // relu2_2
+    int H3 = (H2 + 1) / 2, W3 = (W2 + 1) / 2;
+    TGTC_TRY(pool(buf[2], H2, W2, 128, buf[0]));
+    TGTC_TRY(conv(16, buf[0], H3, W3, 128, 256, buf[1]));            // relu3_1
+    TGTC_TRY(emit(buf[1], H3 * W3, 256, relu3_1));
+    TGTC_TRY(conv(19, buf[1], H3, W3, 256, 256, buf[2]));            // relu3_2
+    TGTC_TRY(conv(22, buf[2], H3, W3, 256, 256, buf[0]));            // relu3_3
+    TGTC_TRY(conv(25, buf[0], H3, W3, 256, 256, buf[1]));            // relu3_4
+    int H4 = (H3 + 1) / 2, W4 = (W3 + 1) / 2;
+    TGTC_TRY(pool(buf[1], H3, W3, 256, buf[2]));
+    TGTC_TRY(conv(29, buf[2], H4, W4, 256, 512, buf[0]));            // relu4_1
+    return emit(buf[0], H4 * W4, 512, relu4_1);
+}
+
+extern "C" int tgtc_s2d_mean_std(const float* feat, int C, int64_t HW, float eps, float* mean, float* std_,
+                                 void* stream) {
+    TGTC_REQUIRE(feat && mean && std_ && C > 0 && HW > 1, "mean_std: bad argument (needs HW > 1 for the unbiased variance)");
+    mean_std_kernel<<<C, 256, 0, as_stream(stream)>>>(feat, HW, eps, mean, std_);
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
+}
+
+extern "C" int tgtc_s2d_adain(const float* content, int64_t HWc, const float* style, int64_t HWs, int C, float* stats,
+                              float* out, void* stream) {
+    TGTC_REQUIRE(content && style && stats && out && C > 0 && HWc > 1 && HWs > 1, "adain: bad argument");
+    hipStream_t st = as_stream(stream);
+    mean_std_kernel<<<C, 256, 0, st>>>(content, HWc, 1e-5f, stats, stats + C);
+    mean_std_kernel<<<C, 256, 0, st>>>(style, HWs, 1e-5f, stats + 2 * C, stats + 3 * C);
+    const long long n = HWc * C;
+    adain_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(content, HWc, C, stats, out);
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
+}
+
+extern "C" int tgtc_s2d_resize_bilinear(const float* in, int C, int h, int w, float* out, int H, int W, void* stream) {
+    TGTC_REQUIRE(in && out && C > 0 && h > 0 && w > 0 && H > 0 && W > 0, "resize_bilinear: bad argument");
+    const long long n = (long long)C * H * W;
+    resize_bilinear_kernel<<<(unsigned)((n + 255) / 256), 256, 0, as_stream(stream)>>>(in, C, h, w, out, H, W);
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
+}
+
+extern "C" int tgtc_s2d_style_feature(const float* hs_tokens, int n_tokens, float* feature, void* stream) {
+    TGTC_REQUIRE(hs_tokens && feature && n_tokens > 1, "style_feature: bad argument");
+    style_feature_kernel<<<512, 256, 0, as_stream(stream)>>>(hs_tokens, n_tokens, feature);
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
+}
+
+extern "C" int tgtc_s2d_tokens_to_nchw(const float* tokens, int n, int C, float* out, void* stream) {
+    TGTC_REQUIRE(tokens && out && n > 0 && C > 0, "tokens_to_nchw: bad argument");
+    dim3 grid((C + 31) / 32, (n + 31) / 32);
+    transpose_kernel<<<grid, 256, 0, as_stream(stream)>>>(tokens, n, C, out);
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
+}
+
+extern "C" int tgtc_s2d_nchw_to_tokens(const float* in, int n, int C, float* tokens, void* stream) {
+    TGTC_REQUIRE(in && tokens && n > 0 && C > 0, "nchw_to_tokens: bad argument");
+    dim3 grid((n + 31) / 32, (C + 31) / 32);
+    transpose_kernel<<<grid, 256, 0, as_stream(stream)>>>(in, C, n, tokens);
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
+}

@@ -65,6 +65,17 @@ _OPTIONAL = {
 }
 
 
+def register(signatures, restypes=None):
+    """Add the entry points of another header (include/tgtc_style2d.h) to the binding table."""
+    _SIGNATURES.update(signatures)
+    _RESTYPES.update(restypes or {})
+    if _lib is not None:
+        for name, argtypes in signatures.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, c_int)
+
+
 def header_symbols():
     """Every entry point include/tgtc_hip.h declares (used by the CPU export test)."""
     return sorted(list(_SIGNATURES) + list(_OPTIONAL))
