@@ -64,3 +64,187 @@ class RayRenderer:
         if want_coarse:
             out["rgb_coarse"], out["t_coarse"] = rgb_c, t_c
         return out
+
+
+# =====================================================================================================
+# Drop-in drivers with the reference's signatures (rendering.py:5, :93-94, :242-243).
+#
+# They accept the same injected callables and the same dataloader / dataset duck types as the reference
+# (a dataloader yields dicts of tensors; `dataloader.dataset` carries cps / cps_valid / hwf / near / far /
+# frame_num / h / w / mode).  With HIP-backed callables from this package every stage runs on the GPU; pass
+# `renderer=RayRenderer(...)` to replace the per-stage chain by the fused single-call path.
+# Unlike the reference they return cleanly and require N_samples_fine > 0 (Q2).
+# =====================================================================================================
+def _save_png(path, arr):
+    from PIL import Image
+    Image.fromarray(np.asarray(arr).astype(np.uint8)).save(path)   # utils.py:463 to8b = uint8 cast
+
+
+def _to_device(batch, device):
+    return {k: torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).to(device) for k, v in batch.items()}
+
+
+def _require_fine(args):
+    if not args.N_samples_fine > 0:
+        raise ValueError("N_samples_fine must be > 0: the reference's render paths dereference None otherwise "
+                         "(rendering.py:186; train_tgtcs.py:184)")
+
+
+def _write_depth_rgb(sv_path, rgb, t, h, w, rgb_name, depth_name):
+    """rendering.py:202-217: per-image min-max depth normalisation, x255, int32, uint8 cast."""
+    sv_t = (t - t.min()) / (t.max() - t.min() + 1e-7)
+    _save_png(os.path.join(sv_path, rgb_name), np.array(rgb.reshape(h, w, 3) * 255, np.int32))
+    _save_png(os.path.join(sv_path, depth_name), np.array(sv_t.reshape(h, w) * 255, np.int32))
+
+
+def cal_geometry(model_forward, samp_func, dataloader, args, device, sv_path=None, model_forward_fine=None,
+                 samp_func_fine=None, renderer=None):
+    """reference rendering.py:5-90: plain NeRF render of every ray the loader yields; writes rgb_%05d.png,
+    depth_%05d.png, geometry_%05d.npz per image and geometry.npz; returns (rgb_map [F,h,w,3], t_map [F,h,w,1])."""
+    from . import utils
+    _require_fine(args)
+    if sv_path is not None:
+        os.makedirs(sv_path, exist_ok=True)
+    ds = dataloader.dataset
+    train = 'train' in ds.mode
+    cps = ds.cps if train else ds.cps_valid
+    frame_num, h, w = (ds.frame_num if train else ds.cps_valid.shape[0]), ds.h, ds.w
+    res = h * w
+    rgb_map = np.zeros([frame_num * res, 3], np.float32)
+    t_map = np.zeros([frame_num * res], np.float32)
+    coor_map = np.zeros([frame_num * res, 3], np.float32)
+    img_id = pixel_id = 0
+    for batch in dataloader:
+        b = _to_device(batch, device)
+        rays_o, rays_d = b['rays_o'], b['rays_d']
+        if renderer is not None:
+            out = renderer.render(rays_o, rays_d, args.N_samples, args.N_samples_fine, near=ds.near, far=ds.far)
+            rgb_f, t_f = out["rgb"], out["t"]
+        else:
+            pts, ts = samp_func(rays_o=rays_o, rays_d=rays_d, N_samples=args.N_samples, near=ds.near, far=ds.far)
+            R = rays_o.shape[0]
+            ret = model_forward(pts=pts, dirs=rays_d.unsqueeze(1).expand([R, args.N_samples, 3]))
+            _, _, weights = utils.alpha_composition(ret['rgb'], ret['sigma'], ts, 0)
+            pts_f, ts_f = samp_func_fine(rays_o, rays_d, ts, weights, args.N_samples_fine)
+            n = args.N_samples + args.N_samples_fine
+            ret = model_forward_fine(pts=pts_f, dirs=rays_d.unsqueeze(1).expand([R, n, 3]))
+            rgb_f, t_f, _ = utils.alpha_composition(ret['rgb'], ret['sigma'], ts_f, 0)
+        rgb_np, t_np = rgb_f.detach().cpu().numpy(), t_f.detach().cpu().numpy()
+        coor = t_np[..., None] * rays_d.detach().cpu().numpy() + rays_o.detach().cpu().numpy()   # rendering.py:54
+        n = coor.shape[0]
+        rgb_map[pixel_id:pixel_id + n], t_map[pixel_id:pixel_id + n], coor_map[pixel_id:pixel_id + n] = rgb_np, t_np, coor
+        pixel_id += n
+        done = pixel_id // res - img_id
+        if done > 0 and sv_path is not None:
+            for i in range(img_id, img_id + done):
+                sl = slice(i * res, (i + 1) * res)
+                _write_depth_rgb(sv_path, rgb_map[sl], t_map[sl], h, w, 'rgb_%05d.png' % i, 'depth_%05d.png' % i)
+                np.savez(os.path.join(sv_path, 'geometry_%05d' % i), coor_map=coor_map[sl].reshape(h, w, 3),
+                         cps=cps[i], hwf=ds.hwf, near=ds.near, far=ds.far)
+        img_id += max(done, 0)
+    rgb_map, t_map = rgb_map.reshape(-1, h, w, 3), t_map.reshape(-1, h, w, 1)
+    if sv_path is not None:
+        np.savez(os.path.join(sv_path, 'geometry'), coor_map=coor_map.reshape(-1, h, w, 3), cps=cps, hwf=ds.hwf,
+                 near=ds.near, far=ds.far)
+    return rgb_map, t_map
+
+
+def _styled_batch(b, args, ds, samp_func, model_forward, style_forward, concat_style_forward, latents_model_1,
+                  model_forward_fine, samp_func_fine, renderer):
+    """One batch of the stylised chain (rendering.py:118-178 == :280-327)."""
+    from . import utils
+    rays_o, rays_d = b['rays_o'], b['rays_d']
+    z = latents_model_1(style_ids=b['style_id'].long(), frame_ids=b['frame_id'].long(), type=args.dataset_type)
+    if renderer is not None:
+        out = renderer.render(rays_o, rays_d, args.N_samples, args.N_samples_fine, near=ds.near, far=ds.far,
+                              jitter=torch.rand(rays_o.shape[0], args.N_samples, device=rays_o.device), z=z)
+        return out["rgb"], out["t"]
+    R, L = rays_o.shape[0], z.shape[-1]
+    zbar = torch.mean(z, dim=1, keepdim=True)                      # rendering.py:126
+
+    def one_pass(fwd, pts, n):
+        ret = fwd(pts=pts, dirs=rays_d.unsqueeze(1).expand([R, n, 3]))
+        cf = concat_style_forward(x=ret['pts'], latent=z.unsqueeze(1).expand([R, n, L]))['concat_features']
+        both = torch.cat((ret['base_remap'], cf), dim=-1)           # rendering.py:132
+        rgb = style_forward(x=ret['pts'], concated=both, latent=zbar.unsqueeze(2).expand([R, n, L]))['rgb']
+        return rgb, ret['sigma']
+
+    pts, ts = samp_func(rays_o=rays_o, rays_d=rays_d, N_samples=args.N_samples, near=ds.near, far=ds.far, perturb=True)
+    rgb, sig = one_pass(model_forward, pts, args.N_samples)
+    _, _, weights = utils.alpha_composition(rgb, sig, ts, 0)
+    pts_f, ts_f = samp_func_fine(rays_o, rays_d, ts, weights, args.N_samples_fine)
+    rgb, sig = one_pass(model_forward_fine, pts_f, args.N_samples + args.N_samples_fine)
+    rgb_f, t_f, _ = utils.alpha_composition(rgb, sig, ts_f, 0)
+    return rgb_f, t_f
+
+
+def render_style(model_forward, samp_func, style_forward, concat_style_forward, latents_model_1, dataloader, args,
+                 device, sv_path=None, model_forward_fine=None, samp_func_fine=None, sigma_scale=0., renderer=None):
+    """reference rendering.py:93-239: stylised render of the `valid_style` rays; one
+    style_%05d_fine_%05d.png + style_%05d_fine_depth_%05d.png pair per completed frame.
+    Returns (rgb_map_fine, t_map_fine) = the rays left over after the last whole image, like the reference."""
+    _require_fine(args)
+    latents_model_1.sigma_scale = sigma_scale
+    if sv_path is not None:
+        os.makedirs(sv_path, exist_ok=True)
+    ds = dataloader.dataset
+    ds.mode = 'valid_style'
+    frame_num, h, w = ds.cps_valid.shape[0], ds.h, ds.w
+    res = h * w
+    pend_rgb, pend_t, image_no = np.zeros([0, 3], np.float32), np.zeros([0], np.float32), 0
+    for batch in dataloader:
+        b = _to_device(batch, device)
+        rgb_f, t_f = _styled_batch(b, args, ds, samp_func, model_forward, style_forward, concat_style_forward,
+                                   latents_model_1, model_forward_fine, samp_func_fine, renderer)
+        pend_rgb = np.concatenate([pend_rgb, rgb_f.detach().cpu().numpy()], 0)
+        pend_t = np.concatenate([pend_t, t_f.detach().cpu().numpy()], 0)
+        while pend_rgb.shape[0] >= res:
+            if sv_path is not None:
+                # file numbering: images are consecutive (style, frame) pairs (rendering.py:209-218)
+                _write_depth_rgb(sv_path, pend_rgb[:res], pend_t[:res], h, w,
+                                 'style_%05d_fine_%05d.png' % (image_no // frame_num, image_no % frame_num),
+                                 'style_%05d_fine_depth_%05d.png' % (image_no // frame_num, image_no % frame_num))
+            image_no += 1
+            pend_rgb, pend_t = pend_rgb[res:], pend_t[res:]
+    return pend_rgb, pend_t
+
+
+def render_train_style(samp_func, model_forward, style_forward, concat_style_forward, latents_model_1, dataset, args,
+                       device, sv_path=None, model_forward_fine=None, samp_func_fine=None, sigma_scale=0.,
+                       renderer=None):
+    """reference rendering.py:242-375: stylised render of the training views in `train_style` order; the batch is the
+    largest divisor of h*w not above --chunk (:251-253); images already on disk are skipped (:267-270); RGB is clamped
+    to [0,1] (:328); depth is min-max normalised without epsilon and written as 3 channels (:358-361)."""
+    _require_fine(args)
+    os.makedirs(sv_path, exist_ok=True)
+    latents_model_1.sigma_scale = sigma_scale
+    frame_num, h, w = dataset.frame_num, dataset.h, dataset.w
+    dataset.mode = 'train_style'
+    batch_size = args.chunk
+    while (h * w) % batch_size != 0:
+        batch_size -= 1
+    iters_per_image = (h * w) // batch_size
+    loader = dataset.batches(batch_size) if hasattr(dataset, 'batches') else torch.utils.data.DataLoader(
+        dataset, shuffle=False, batch_size=batch_size, num_workers=getattr(args, 'num_workers', 0))
+    it = img_count = 0
+    rgbs, ts = [], []
+    for batch in loader:
+        path = os.path.join(sv_path, 'style_%05d_fine_%05d.png' % (img_count // frame_num, img_count % frame_num))
+        exists = os.path.exists(path)
+        if not exists:
+            b = _to_device(batch, device)
+            rgb_f, t_f = _styled_batch(b, args, dataset, samp_func, model_forward, style_forward, concat_style_forward,
+                                       latents_model_1, model_forward_fine, samp_func_fine, renderer)
+            rgbs.append(torch.clamp(rgb_f, 0., 1.).detach().cpu().numpy())
+            ts.append(t_f.detach().cpu().numpy())
+        it += 1
+        if it == iters_per_image:
+            if not exists:
+                rgb = np.concatenate(rgbs, 0).reshape(h, w, 3)
+                t = np.broadcast_to(np.concatenate(ts, 0).reshape(h, w)[..., None], [h, w, 3])
+                t = (t - t.min()) / (t.max() - t.min())
+                _save_png(path, np.array(rgb * 255, np.int32))
+                _save_png(path.replace('_fine_', '_fine_depth_'), np.array(t * 255, np.int32))
+            img_count += 1
+            it, rgbs, ts = 0, [], []
+    return img_count

@@ -1,0 +1,154 @@
+"""`python -m tgtc_style_amd.train_tgtcs --config configs/fern.txt --render_valid_style [--synthetic]`
+
+The render half of the reference entry point (train_tgtcs.py:13-215): build the four networks and the latent
+table, reload the newest checkpoints, and dispatch to render_style / render_train_style (or cal_geometry with
+--render_valid).  Output directory and file names are the reference's (train_tgtcs.py:20,164,196;
+rendering.py:216-217,363-364).  Training loops are out of scope.
+
+No dataset or checkpoint ships with this repository (and the LLFF loader is a `next` row of SURVEY section 8f), so
+`--synthetic` provides a seeded scene: synth.nerf_state/... weights and a closed-form camera path.  Without it
+the reference layout is expected: <sv_path>/NNNNNN.tar, style_NNNNNN.tar, latent_NNNNNN.tar.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import config as cfg
+from . import models, rendering, synth, utils
+
+
+class SyntheticScene:
+    """Duck type of the reference datasets for the render drivers (dataset.py:361-470 attributes), with rays
+    generated on the device per frame instead of stored float64 tables (dataset.py:412-433)."""
+
+    def __init__(self, h, w, frames, valid_frames, device="cuda", style_num=1):
+        self.h, self.w, self.f = h, w, synth.fern_intrinsics(h, w)
+        self.hwf = [h, w, self.f]
+        self.near, self.far = 0., 1.
+        to44 = lambda p: np.concatenate([p, np.array([[0, 0, 0, 1]], np.float32)], 0)
+        self.cps = np.stack([to44(synth.spiral_pose(7 * i)) for i in range(frames)])
+        self.cps_valid = np.stack([to44(synth.spiral_pose(i, n=valid_frames)) for i in range(valid_frames)])
+        self.frame_num, self.style_num = frames, style_num
+        self.mode, self.device = 'train', device
+
+    def batches(self, batch_size):
+        poses = self.cps if 'train' in self.mode else self.cps_valid
+        n_img = len(poses) * (self.style_num if 'style' in self.mode else 1)
+        for k in range(n_img):
+            sid, fid = divmod(k, len(poses))
+            o, d = utils.gen_rays(self.h, self.w, self.f, poses[fid][:3, :4], device=self.device)
+            for lo in range(0, self.h * self.w, batch_size):
+                n = min(batch_size, self.h * self.w - lo)
+                yield {'rays_o': o[lo:lo + n], 'rays_d': d[lo:lo + n],
+                       'style_id': torch.full((n,), sid, dtype=torch.long), 'frame_id': torch.full((n,), fid, dtype=torch.long)}
+
+
+class _Loader:
+    def __init__(self, dataset, batch_size):
+        self.dataset, self.batch_size = dataset, batch_size
+
+    def __iter__(self):
+        return self.dataset.batches(self.batch_size)
+
+
+def _t(sd):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+
+def _newest(path, want, reject=()):
+    files = [f for f in sorted(os.listdir(path)) if 'tar' in f and all(w in f for w in want) and not any(r in f for r in reject)]
+    return os.path.join(path, files[-1]) if files else None
+
+
+def train(args):
+    if not torch.cuda.is_available():
+        raise SystemExit("train_tgtcs: no GPU visible; the HIP render path has no CPU fallback")
+    device = torch.device("cuda")
+    use_viewdir_str = '_UseViewDir_' if args.use_viewdir else ''
+    sv_path = os.path.join(args.basedir, args.expname + '_' + args.nerf_type + '_' + args.act_type + use_viewdir_str +
+                           'ImgFactor' + str(int(args.factor)))        # train_tgtcs.py:19-20
+    os.makedirs(sv_path, exist_ok=True)
+
+    model = models.StyleNerf(args, mode='coarse').to(device)
+    model_fine = models.StyleNerf(args, mode='fine').to(device)
+    concat_model = models.StyleMLP_before_concat(args).to(device)
+    style_model = models.StyleMLP_Wild_multilayers(args).to(device)
+    global_step = 0
+    ck = None if args.no_reload else _newest(sv_path, ['tar'], ['style', 'latent'])      # train_tgtcs.py:60-72
+    if ck:
+        sd = torch.load(ck, map_location='cpu')
+        global_step = sd['global_step']
+        model.load_state_dict(sd['model'])
+        model_fine.load_state_dict(sd['model_fine'])
+    elif args.synthetic:
+        model.load_state_dict(_t(synth.nerf_state(0)))
+        model_fine.load_state_dict(_t(synth.nerf_state(1)))
+    else:
+        raise SystemExit("train_tgtcs: no NeRF checkpoint in %s (use --synthetic for the seeded scene)" % sv_path)
+    ck = None if args.no_reload else _newest(sv_path, ['tar', 'style'], ['latent'])       # train_tgtcs.py:74-82
+    if ck:
+        sd = torch.load(ck, map_location='cpu')
+        global_step = sd['global_step']
+        style_model.load_state_dict(sd['model'])
+        concat_model.load_state_dict(sd['concat_model'])
+    elif args.synthetic:
+        concat_model.load_state_dict(_t(synth.concat_state(2)))
+        style_model.load_state_dict(_t(synth.style_state(3)))
+
+    if not args.synthetic:
+        raise SystemExit("train_tgtcs: the LLFF dataset loader is not part of this build (SURVEY section 8f); "
+                         "run with --synthetic")
+    hw = args.synthetic_hw
+    dataset = SyntheticScene(hw, hw, frames=20, valid_frames=args.synthetic_frames, device=device)
+    latents = models.StyleLatents_variational(style_num=dataset.style_num, frame_num=dataset.frame_num,
+                                              latent_dim=args.vae_latent).to(device)
+    ck = None if args.no_reload else _newest(sv_path, ['tar', 'latent'], ['style'])       # train_tgtcs.py:139-146
+    if ck:
+        latents.load_state_dict(torch.load(ck, map_location='cpu')['train_set_1'])
+    else:
+        latents.load_state_dict(_t(synth.latents_state(4, style_num=dataset.style_num, frame_num=dataset.frame_num)))
+    latents = latents.to(device)
+
+    renderer = rendering.RayRenderer(model, model_fine, models.StylePair(concat_model, style_model))
+    common = dict(samp_func=utils.sampling_pts_uniform, model_forward=utils.batchify(lambda **kw: model(**kw), args.chunk),
+                  model_forward_fine=utils.batchify(lambda **kw: model_fine(**kw), args.chunk),
+                  samp_func_fine=utils.sampling_pts_fine_torch, args=args, device=device)
+    styled = dict(style_forward=utils.batchify(lambda **kw: style_model(**kw), args.chunk),
+                  concat_style_forward=utils.batchify(lambda **kw: concat_model(**kw), args.chunk),
+                  latents_model_1=latents, sigma_scale=args.sigma_scale, renderer=renderer)
+    with torch.no_grad():
+        if args.render_valid_style:
+            out = os.path.join(sv_path, 'render_valid_' + str(global_step))
+            model.set_enable_style(True), model_fine.set_enable_style(True)
+            dataset.mode = 'valid_style'
+            rendering.render_style(dataloader=_Loader(dataset, args.batch_size), sv_path=out, **common, **styled)
+            print('Done, saving to', out)
+            return out
+        if args.render_train_style:
+            out = os.path.join(sv_path, 'render_train_' + str(global_step))
+            model.set_enable_style(True), model_fine.set_enable_style(True)
+            rendering.render_train_style(dataset=dataset, sv_path=out, **common, **styled)
+            print('Done, saving to', out)
+            return out
+        if args.render_valid or args.render_train:
+            out = os.path.join(sv_path, 'nerf_gen_data2')
+            dataset.mode = 'train' if args.render_train else 'valid'
+            rendering.cal_geometry(dataloader=_Loader(dataset, args.batch_size), sv_path=out,
+                                   renderer=rendering.RayRenderer(model, model_fine), **common)
+            print('Done, saving to', out)
+            return out
+    raise SystemExit("train_tgtcs: nothing to do -- pass --render_valid_style, --render_train_style or --render_valid "
+                     "(the training loops of the reference are outside this build)")
+
+
+def main(argv=None):
+    args = cfg.parse_args(argv)
+    if args.expname is None:
+        raise SystemExit("train_tgtcs: --expname (or --config) is required")
+    return train(args)      # the reference wraps this in `while True` (train_tgtcs.py:596-597); once is enough
+
+
+if __name__ == '__main__':
+    main()
