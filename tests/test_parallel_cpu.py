@@ -33,7 +33,7 @@ def _worker(rank, world, port, n_pixels, q):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     frame = parallel.render_frame_sharded(_fake_render, _fake_rays, n_pixels, rank, world, dist)
-    q.put((rank, frame))
+    q.put((rank, frame.numpy()))     # by value: tensors would travel as shared-memory handles
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,7 +53,7 @@ def test_sharded_frame_equals_whole(world, n_pixels):
     rgb, t = _fake_render(*_fake_rays(0, n_pixels))
     whole = torch.cat([rgb, t[:, None]], 1)
     for r in range(world):
-        assert torch.equal(got[r], whole)
+        assert torch.equal(torch.from_numpy(got[r]), whole)
 
 
 def test_shard_ranges_partition():
