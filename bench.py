@@ -34,6 +34,10 @@ MAC_FULL = 593408          # MACs per sample, full NeRF
 MAC_SIGMA = 491264         # MACs per sample, trunk + sigma head
 FLOP_PER_RAY = 2 * (N_COARSE * MAC_SIGMA + (N_COARSE + N_FINE) * MAC_FULL)   # 353.6 MFLOP
 PEAK_FP16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
+# HBM bytes of one fine-pass launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
+# WRITE_SIZE collected in separate --pmc runs; FETCH_SIZE calibrated 1:1 on the known 4-B-per-lane depth reads
+# of this kernel, see profiles/r1_pmc_summary.md).  bench.py cannot collect counters itself.
+PMC_TRAFFIC_BYTES = {"fp16x3": (119542.14 + 480000.0) * 1024, "fp16": None}
 
 
 class NetArgs:
@@ -89,7 +93,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="fp16x3", choices=["fp16x3", "fp16"])
-    ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the CPU baseline sample (0 disables)")
+    ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the CPU baseline sample (0 disables)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -175,7 +179,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "nerf_mlp_kernel<FULL> (fine pass: PE + 12 dense layers, %d samples)"
                                                    % (n_rays * (N_COARSE + N_FINE)),
                          "achieved": achieved, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP16_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP16_TFLOPS, "traffic": PMC_TRAFFIC_BYTES.get(args.precision),
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/)",
+                         "algorithmic_bytes_per_launch": n_rays * (N_COARSE + N_FINE) * 20,
                          "kernel_ms": kernel_ms, "algorithmic_tflop_per_launch": flop_launch / 1e12,
                          "mfma_products_per_algorithmic_product": mfma_per_product,
                          "mfma_pipe_frac": achieved * mfma_per_product / PEAK_FP16_TFLOPS},

@@ -98,6 +98,10 @@ int tgtc_nerf_forward_rays(const tgtc_net* net, const double* rays_o, const doub
  * sigma-only kernel of a fused render's coarse pass).  One-shot.  Used by bench.py for the roofline figure. */
 int tgtc_time_next_nerf_launch(int full, void* start_event, void* stop_event);
 
+/* Diagnostics: while buf != NULL, the first 64 workgroups of every fused NeRF launch of the calling thread write
+ * s_memtime stamps of their phase boundaries into buf ([64][4 waves][32] uint64).  Never set in production. */
+int tgtc_debug_set_stamps(void* buf);
+
 /* ------------------------------------------------------------------ a6: alpha compositing
  * utils.py:354-386 alpha_composition with sigma_noise_std=0, white_bkgd=False.  weights may be NULL. */
 int tgtc_composite(const float* rgb, const float* sigma, const float* ts, int64_t R, int N,

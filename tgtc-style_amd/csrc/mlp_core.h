@@ -53,11 +53,12 @@ constexpr int kRingSlots = 8;             // 128 KiB ring
 constexpr int kRingBytes = kChunkBytes * kRingSlots;
 constexpr int kPrefetchDepth = kRingSlots - 1;
 
-template <int NWAVES_, int NCT_, bool SPLIT_>
+template <int NWAVES_, int NCT_, bool SPLIT_, int G_ = (SPLIT_ ? 4 : 8)>
 struct MlpCfg {
     static constexpr int NWAVES = NWAVES_;
     static constexpr int NCT = NCT_;                       // 16-sample column tiles per wave
     static constexpr bool SPLIT = SPLIT_;
+    static constexpr int G = G_;                           // fragments per LDS->register staging group
     static constexpr int FRAG_BYTES = SPLIT ? 2048 : 1024;  // hi (+ lo) fragment
     static constexpr int FPC = kChunkBytes / FRAG_BYTES;    // fragments per chunk
     static constexpr int GPC = kChunkBytes / (NWAVES * 1024);  // LDS-DMA instructions per wave per chunk
@@ -105,8 +106,10 @@ struct WeightStream {
     // MFMAs of group g run.  (hipcc only ever emits `s_waitcnt lgkmcnt(0)` here, never a counted wait,
     // so each wait must find every outstanding read already old: one burst per group, issued right
     // after the previous group's wait.)
-    static constexpr int G = C::SPLIT ? 2 : 4;
+    static constexpr int G = C::G;
     static_assert(C::FPC % G == 0 && 2 * G <= C::FPC, "groups must tile a chunk and stay within one chunk of look-ahead");
+    // LDS reads this window issues (fragments 2k, 2k+1 of the NEXT group while 2k < G), hi (+ lo) each
+    static constexpr int reads_in_window(int f) { return (2 * (f % G) < G ? 2 : 0) * (C::SPLIT ? 2 : 1); }
 
     const char* src[Map::NSEG];  // per-lane: segment stream + wave*GPC*1024 + lane*16
     char* lds_wave;              // wave-uniform: ring + wave*GPC*1024
@@ -162,6 +165,7 @@ struct WeightStream {
         wait_vmcnt<(issued_last - need) * C::GPC>();
         __builtin_amdgcn_s_barrier();
         static_for<G>([&](auto f) { fetch<decltype(f)::value>(); });
+        __builtin_amdgcn_sched_barrier(0);
     }
     template <int CH>
     __device__ __forceinline__ void boundary() const {
@@ -172,23 +176,40 @@ struct WeightStream {
             issue<CH + kRingSlots - 1>();
         }
     }
-    // fragment F (hi [+lo]).  On the first fragment of a group: retire the group's reads, then launch
-    // the next group's burst into the other buffer.
+    // fragment F (hi [+lo]).  On the first fragment of a group the group's reads are retired (hipcc only emits
+    // lgkmcnt(0), so every outstanding read must be old by then); the NEXT group's reads are issued two
+    // fragments per window over the first half of the current group, so that each ds_read hides in an MFMA's
+    // issue shadow and the youngest one is >= G/2 windows old at the next wait.  The caller closes the window
+    // with close_window<F>().
     template <int F>
     __device__ __forceinline__ void get(half8& ah, half8& al) {
         constexpr int buf = (F / G) & 1, k = F % G;
         if constexpr (k == 0) {
             if constexpr (F % C::FPC == 0 && F > 0) boundary<F / C::FPC>();
 #pragma unroll
-            for (int j = 0; j < G; ++j) {  // a "use": the compiler's lgkmcnt wait lands HERE, before the burst
+            for (int j = 0; j < G; ++j) {  // a "use": the compiler's lgkmcnt wait lands HERE
                 asm volatile("" ::"v"(qh[buf][j]));
                 if constexpr (C::SPLIT) asm volatile("" ::"v"(ql[buf][j]));
             }
-            static_for<G>([&](auto j) { fetch<F + G + decltype(j)::value>(); });
         }
         ah = qh[buf][k];
         if constexpr (C::SPLIT) al = ql[buf][k];
-        __builtin_amdgcn_sched_barrier(0);  // pin: the burst stays ahead of this group's MFMAs
+        if constexpr (2 * k < G) {
+            fetch<F - k + G + 2 * k>();
+            fetch<F - k + G + 2 * k + 1>();
+        }
+    }
+    // Pin the window's instruction mix: after every MFMA one pending ds_read (if any) and up to two VALU
+    // instructions -- what fits into the ~8 spare issue cycles of a 16x16x32 MFMA -- then fence the window.
+    template <int F, int N_MFMA, int EXTRA_READS>
+    __device__ __forceinline__ void close_window() const {
+        constexpr int NR = reads_in_window(F) + EXTRA_READS;
+        static_for<N_MFMA>([&](auto i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            if constexpr (decltype(i_)::value < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // VALU
+        });
+        __builtin_amdgcn_sched_barrier(0);
     }
     // consume fragments [F0, F0+N) without using them (alignment gaps between segments)
     template <int F0, int N>
@@ -196,6 +217,7 @@ struct WeightStream {
         static_for<N>([&](auto i) {
             half8 a, b;
             get<F0 + decltype(i)::value>(a, b);
+            __builtin_amdgcn_sched_barrier(0);
         });
     }
 };
@@ -206,15 +228,17 @@ __device__ __forceinline__ float4v mfma16(half8 a, half8 b, float4v c) {
 
 // One dense layer.  B operands: Bh[KS][NCT] (+ Bl in split mode).  Fragment (rt,ks) is stream
 // fragment FRAG0 + rt*KS + ks.  bias_lane = LDS address of (bias table) + 4*(lane>>4) floats.
-// epi(ic<rt>, ic<c>, acc) receives the fp32 tile of row tile rt, column tile c:
-//   rows 16*rt + 4*(lane>>4) + r (r = 0..3), column = sample lane&15.
-// The epilogue of row tile rt is issued, one column tile at a time, behind the first MFMAs of row
-// tile rt+1 (two accumulator sets), so its VALU work runs in the shadow of the matrix pipe.
+// epi(ic<rt>, ic<c>, ic<half>, acc) receives one half (registers 2*half, 2*half+1) of the fp32 tile of row
+// tile rt, column tile c:  rows 16*rt + 4*(lane>>4) + r, column = sample lane&15.
+// The epilogue of row tile rt is issued in 2*NCT small units spread evenly behind the MFMAs of row
+// tile rt+1 (two accumulator sets): a 16x16x32 MFMA leaves ~8 of its 16 cycles of issue bandwidth, i.e.
+// one or two VALU instructions, so the ReLU / convert work must trickle, not burst.
 template <class C, int FRAG0, int KS, int RT, int BIAS0, class StreamT, class Epi>
 __device__ __forceinline__ void dense_layer(StreamT& st, lds_cptr bias_lane, const half8 (&Bh)[KS][C::NCT],
                                             const half8 (&Bl)[KS][C::NCT], Epi&& epi) {
     constexpr int NCT = C::NCT;
-    constexpr int PER = (NCT + KS - 1) / KS;  // column tiles of the pending epilogue handled per k-step
+    constexpr int UNITS = 2 * NCT;
+    constexpr int PER = (UNITS + KS - 1) / KS;  // epilogue units per k-step window
     typedef __attribute__((address_space(3))) const float4v* lds_f4;
     float4v acc[2][NCT];
     float4v bias[2];  // read one row tile ahead so that its wait never lands on a fresh burst
@@ -239,13 +263,17 @@ __device__ __forceinline__ void dense_layer(StreamT& st, lds_cptr bias_lane, con
             }
             if constexpr (rt > 0) {
                 static_for<PER>([&](auto p_) {
-                    constexpr int c = ks * PER + decltype(p_)::value;
-                    if constexpr (c < NCT) epi(ic<rt - 1>{}, ic<c>{}, acc[cur ^ 1][c]);
+                    constexpr int u = ks * PER + decltype(p_)::value;
+                    if constexpr (u < UNITS) epi(ic<rt - 1>{}, ic<u / 2>{}, ic<u % 2>{}, acc[cur ^ 1][u / 2]);
                 });
             }
+            st.template close_window<FRAG0 + rt * KS + ks, NCT * (C::SPLIT ? 3 : 1), (ks == 0 && rt + 1 < RT) ? 1 : 0>();
         });
     });
-    static_for<NCT>([&](auto c_) { epi(ic<RT - 1>{}, c_, acc[(RT - 1) & 1][decltype(c_)::value]); });
+    static_for<UNITS>([&](auto u_) {
+        constexpr int u = decltype(u_)::value;
+        epi(ic<RT - 1>{}, ic<u / 2>{}, ic<u % 2>{}, acc[(RT - 1) & 1][u / 2]);
+    });
 }
 
 __device__ __forceinline__ float relu(float v) {
@@ -253,16 +281,27 @@ __device__ __forceinline__ float relu(float v) {
     return __builtin_bit_cast(float, max(__builtin_bit_cast(int, v), 0));
 }
 
-// ReLU + fp16 (hi/lo) conversion of one accumulator tile into the next layer's B fragment:
-// output row tile rt feeds k-step rt/2, elements (rt&1)*4 + r.
-template <class C, int RT_IDX>
+// ReLU + fp16 (hi/lo) conversion of one HALF (registers 2*HALF, 2*HALF+1) of an accumulator tile into the
+// next layer's B fragment: output row tile rt feeds k-step rt/2, elements (rt&1)*4 + r.
+// fp16 mode: convert the pair first (v_cvt_pk_f16_f32), then one packed max (v_pk_max_f16) -- rounding
+// is monotonic and sign preserving, so relu(cvt(x)) == cvt(relu(x)).
+template <class C, int RT_IDX, int HALF>
 __device__ __forceinline__ void store_act(const float4v& acc, half8& yh, half8& yl) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    constexpr int e0 = (RT_IDX & 1) * 4 + 2 * HALF;
+    if constexpr (!C::SPLIT) {
+        half2v h = __builtin_convertvector((float2v{acc[2 * HALF], acc[2 * HALF + 1]}), half2v);
+        h = __builtin_elementwise_max(h, (half2v{(half_t)0, (half_t)0}));
+        yh[e0] = h[0], yh[e0 + 1] = h[1];
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float v = relu(acc[r]);
-        const half_t h = (half_t)v;
-        yh[(RT_IDX & 1) * 4 + r] = h;
-        if constexpr (C::SPLIT) yl[(RT_IDX & 1) * 4 + r] = (half_t)(v - (float)h);
+        for (int r = 0; r < 2; ++r) {
+            const float v = relu(acc[2 * HALF + r]);
+            const half_t h = (half_t)v;
+            yh[e0 + r] = h;
+            yl[e0 + r] = (half_t)(v - (float)h);
+        }
     }
 }
 

@@ -28,6 +28,9 @@ struct NerfArgs {
     float* remap;
     float* out_pts_enc;
     float* out_dirs_enc;
+    // diagnostics (null in production): s_memtime stamps of the first 64 workgroups' waves at phase boundaries,
+    // [block][wave][32] -- only this buffer ever receives them
+    unsigned long long* stamps;
 };
 
 template <class C, int IN_MODE, bool FULL>
@@ -44,6 +47,11 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) nerf_mlp_kernel(NerfArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, n = lane & 15;
     const long long s_wave = (long long)blockIdx.x * C::SAMPLES_PER_WG + wave * C::SAMPLES_PER_WAVE;
+    auto stamp = [&](int i) {
+        if (a.stamps && blockIdx.x < 64 && lane == 0)
+            a.stamps[((size_t)blockIdx.x * C::NWAVES + wave) * 32 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
 
     // ---- 1. inputs (ordinary loads first: once LDS-DMA is in flight hipcc drains vmcnt(0) for them)
     double pos[NCT][3], dir[NCT][3];
@@ -92,6 +100,7 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) nerf_mlp_kernel(NerfArgs a)
     for (int j = 0; j < kNerfBiasBytes / (C::NWAVES * 1024); ++j)
         __builtin_amdgcn_global_load_lds(TGTC_GPTR(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16),
                                          TGTC_LPTR(smem + kRingBytes + (j * C::NWAVES + wave) * 1024), 16, 0, 0);
+    stamp(1);
     ws.prologue();
 
     // ---- 3. positional encoding into B fragments (overlaps the prefetch latency)
@@ -110,24 +119,31 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) nerf_mlp_kernel(NerfArgs a)
     }
 
     const lds_cptr bias_lane = opaque((lds_cptr)smem + kRingBytes + 16 * g);
+    stamp(2);
     ws.start();
+    stamp(3);
 
     // ---- 4. trunk
     half8 Xh[8][NCT], Xl[8][NCT], Yh[8][NCT], Yl[8][NCT];
-    auto to_Y = [&](auto rt_, auto c_, const float4v& acc) {
+    auto to_Y = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
         constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-        store_act<C, rt>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
+        store_act<C, rt, decltype(h_)::value>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
     };
-    auto to_X = [&](auto rt_, auto c_, const float4v& acc) {
+    auto to_X = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
         constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-        store_act<C, rt>(acc, Xh[rt / 2][c], Xl[rt / 2][c]);
+        store_act<C, rt, decltype(h_)::value>(acc, Xh[rt / 2][c], Xl[rt / 2][c]);
     };
 
     dense_layer<C, L::frag0(0), 2, 16, L::bias0(0)>(ws, bias_lane, pe_h, pe_l, to_Y);
+    stamp(4);
     dense_layer<C, L::frag0(1), 8, 16, L::bias0(1)>(ws, bias_lane, Yh, Yl, to_X);
+    stamp(5);
     dense_layer<C, L::frag0(2), 8, 16, L::bias0(2)>(ws, bias_lane, Xh, Xl, to_Y);
+    stamp(6);
     dense_layer<C, L::frag0(3), 8, 16, L::bias0(3)>(ws, bias_lane, Yh, Yl, to_X);
+    stamp(7);
     dense_layer<C, L::frag0(4), 8, 16, L::bias0(4)>(ws, bias_lane, Xh, Xl, to_Y);
+    stamp(8);
     {
         // skip layer: reference input is cat(pe, h) (models.py:98-99); k order here is [h | pe]
         half8 Bh[10][NCT], Bl[10][NCT];
@@ -139,25 +155,28 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) nerf_mlp_kernel(NerfArgs a)
         }
         dense_layer<C, L::frag0(5), 10, 16, L::bias0(5)>(ws, bias_lane, Bh, Bl, to_X);
     }
+    stamp(9);
     dense_layer<C, L::frag0(6), 8, 16, L::bias0(6)>(ws, bias_lane, Xh, Xl, to_Y);
+    stamp(10);
     dense_layer<C, L::frag0(7), 8, 16, L::bias0(7)>(ws, bias_lane, Yh, Yl, to_X);
+    stamp(11);
 
     // ---- 5. sigma head (models.py:103): row 0 of a 16-row tile -> lanes 0..15, register 0
-    dense_layer<C, L::frag0(8), 8, 1, L::bias0(8)>(ws, bias_lane, Xh, Xl, [&](auto, auto c_, const float4v& acc) {
+    dense_layer<C, L::frag0(8), 8, 1, L::bias0(8)>(ws, bias_lane, Xh, Xl, [&](auto, auto c_, auto h_, const float4v& acc) {
         constexpr int c = decltype(c_)::value;
-        if (g == 0 && a.sigma && sidx[c] < a.M) a.sigma[sidx[c]] = acc[0];
+        if constexpr (decltype(h_)::value == 0)
+            if (g == 0 && a.sigma && sidx[c] < a.M) a.sigma[sidx[c]] = acc[0];
     });
 
+    stamp(12);
     if constexpr (FULL) {
         // ---- 6. base_remap (models.py:106) and the colour head (models.py:107-111)
-        dense_layer<C, L::frag0(9), 8, 16, L::bias0(9)>(ws, bias_lane, Xh, Xl, [&](auto rt_, auto c_, const float4v& acc) {
-            constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-            store_act<C, rt>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
+        dense_layer<C, L::frag0(9), 8, 16, L::bias0(9)>(ws, bias_lane, Xh, Xl, [&](auto rt_, auto c_, auto h_, const float4v& acc) {
+            constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value, hf = decltype(h_)::value;
+            store_act<C, rt, hf>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
             if (a.remap && sidx[c] < a.M) {
-                float4v v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = relu(acc[r]);
-                *reinterpret_cast<float4v*>(a.remap + sidx[c] * 256 + 16 * rt + 4 * g) = v;
+                float* o = a.remap + sidx[c] * 256 + 16 * rt + 4 * g + 2 * hf;
+                o[0] = relu(acc[2 * hf]), o[1] = relu(acc[2 * hf + 1]);
             }
         });
         half8 Zh[4][NCT], Zl[4][NCT];
@@ -169,18 +188,19 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) nerf_mlp_kernel(NerfArgs a)
                 for (int k = 0; k < 8; ++k) Bh[k][c] = Yh[k][c], Bl[k][c] = Yl[k][c];
                 Bh[8][c] = de_h[0][c], Bl[8][c] = de_l[0][c];
             }
-            dense_layer<C, L::frag0(10), 9, 8, L::bias0(10)>(ws, bias_lane, Bh, Bl, [&](auto rt_, auto c_, const float4v& acc) {
+            dense_layer<C, L::frag0(10), 9, 8, L::bias0(10)>(ws, bias_lane, Bh, Bl, [&](auto rt_, auto c_, auto h_, const float4v& acc) {
                 constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-                store_act<C, rt>(acc, Zh[rt / 2][c], Zl[rt / 2][c]);
+                store_act<C, rt, decltype(h_)::value>(acc, Zh[rt / 2][c], Zl[rt / 2][c]);
             });
         }
-        dense_layer<C, L::frag0(11), 4, 1, L::bias0(11)>(ws, bias_lane, Zh, Zl, [&](auto, auto c_, const float4v& acc) {
-            constexpr int c = decltype(c_)::value;
+        dense_layer<C, L::frag0(11), 4, 1, L::bias0(11)>(ws, bias_lane, Zh, Zl, [&](auto, auto c_, auto h_, const float4v& acc) {
+            constexpr int c = decltype(c_)::value, hf = decltype(h_)::value;
             if (g == 0 && a.rgb && sidx[c] < a.M) {
 #pragma unroll
-                for (int r = 0; r < 3; ++r) a.rgb[sidx[c] * 3 + r] = 1.0f / (1.0f + expf(-acc[r]));
+                for (int r = 2 * hf; r < (hf ? 3 : 2); ++r) a.rgb[sidx[c] * 3 + r] = 1.0f / (1.0f + expf(-acc[r]));
             }
         });
+        stamp(13);
     }
 }
 
@@ -204,6 +224,7 @@ static std::vector<LayerSpec> nerf_specs(const tgtc_linear* l) {
 
 // Measurement hook (bench.py): HIP events recorded on the launch stream around the next FULL / sigma-only
 // launch, so the kernel's duration is measured live inside the timed region.  Thread-local, one-shot.
+static thread_local unsigned long long* g_stamps = nullptr;  // diagnostics, see tgtc_debug_set_stamps
 static thread_local hipEvent_t g_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
 
 template <class C, int IN_MODE, bool FULL>
@@ -226,8 +247,16 @@ template <int IN_MODE, bool FULL>
 static int dispatch_nerf(const tgtc_net* net, NerfArgs& a, hipStream_t st) {
     a.bias = net->dev;
     a.stream = net->dev + net->bias_bytes;
+    a.stamps = g_stamps;
+#ifdef TGTC_DEV_VARIANT   // development builds: only the hot-path kernels of one experimental configuration
+    if constexpr (IN_MODE == IN_RAYS) {
+        if (net->precision == TGTC_PREC_FP16) return launch_nerf<TGTC_DEV_VARIANT, IN_MODE, FULL>(a, st);
+    }
+    return fail(TGTC_ERR_UNSUPPORTED, "development build: kernel not compiled");
+#else
     if (net->precision == TGTC_PREC_FP16) return launch_nerf<CfgFast, IN_MODE, FULL>(a, st);
     return launch_nerf<CfgExact, IN_MODE, FULL>(a, st);
+#endif
 }
 
 int nerf_forward_rays_impl(const tgtc_net* net, const double* rays_o, const double* rays_d, const float* ts, int64_t R,
@@ -297,6 +326,11 @@ extern "C" int tgtc_time_next_nerf_launch(int full, void* start_event, void* sto
     TGTC_REQUIRE(full == 0 || full == 1, "time_next_nerf_launch: full must be 0 (sigma-only) or 1");
     g_ev[full][0] = reinterpret_cast<hipEvent_t>(start_event);
     g_ev[full][1] = reinterpret_cast<hipEvent_t>(stop_event);
+    return TGTC_OK;
+}
+
+extern "C" int tgtc_debug_set_stamps(void* buf) {  // [64 blocks][4 waves][32] uint64, or NULL to disable
+    g_stamps = static_cast<unsigned long long*>(buf);
     return TGTC_OK;
 }
 

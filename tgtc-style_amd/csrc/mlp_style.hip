@@ -89,13 +89,13 @@ __device__ __forceinline__ void concat_mlp(WS& ws, lds_cptr bias_lane, const hal
                                            const half8 (&z_l)[C::NCT], half8 (&Xh)[8][C::NCT], half8 (&Xl)[8][C::NCT],
                                            half8 (&Yh)[8][C::NCT], half8 (&Yl)[8][C::NCT]) {
     constexpr int NCT = C::NCT;
-    auto to_Y = [&](auto rt_, auto c_, const float4v& acc) {
+    auto to_Y = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
         constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-        store_act<C, rt>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
+        store_act<C, rt, decltype(h_)::value>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
     };
-    auto to_X = [&](auto rt_, auto c_, const float4v& acc) {
+    auto to_X = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
         constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-        store_act<C, rt>(acc, Xh[rt / 2][c], Xl[rt / 2][c]);
+        store_act<C, rt, decltype(h_)::value>(acc, Xh[rt / 2][c], Xl[rt / 2][c]);
     };
     {
         half8 Bh[3][NCT], Bl[3][NCT];
@@ -133,13 +133,13 @@ __device__ __forceinline__ void style_tail(WS& ws, lds_cptr bias_lane, const hal
                                            const half8 (&z_l)[C::NCT], half8 (&Xh)[8][C::NCT], half8 (&Xl)[8][C::NCT],
                                            half8 (&Yh)[8][C::NCT], half8 (&Yl)[8][C::NCT], Emit&& emit) {
     constexpr int NCT = C::NCT;
-    auto to_Y = [&](auto rt_, auto c_, const float4v& acc) {
+    auto to_Y = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
         constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-        store_act<C, rt>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
+        store_act<C, rt, decltype(h_)::value>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
     };
-    auto to_X = [&](auto rt_, auto c_, const float4v& acc) {
+    auto to_X = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
         constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-        store_act<C, rt>(acc, Xh[rt / 2][c], Xl[rt / 2][c]);
+        store_act<C, rt, decltype(h_)::value>(acc, Xh[rt / 2][c], Xl[rt / 2][c]);
     };
     auto hidden = [&](auto layer_, const half8 (&Ah)[8][NCT], const half8 (&Al)[8][NCT], auto&& epi) {
         constexpr int l = decltype(layer_)::value;
@@ -163,7 +163,7 @@ __device__ __forceinline__ void style_tail(WS& ws, lds_cptr bias_lane, const hal
     }
     hidden(ic<5>{}, Xh, Xl, to_Y);
     hidden(ic<6>{}, Yh, Yl, to_X);
-    hidden(ic<7>{}, Xh, Xl, [&](auto, auto c_, const float4v& acc) { emit(c_, acc); });
+    hidden(ic<7>{}, Xh, Xl, [&](auto, auto c_, auto h_, const float4v& acc) { emit(c_, h_, acc); });
 }
 
 template <bool SPLIT>
@@ -263,13 +263,13 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) styled_rays_kernel(StyledAr
             for (int c = 0; c < NCT; ++c) stash_store<C>(slab, tid, ks, c, Yh[ks][c], Yl[ks][c]);
 
         // ---- NeRF trunk (models.py:95-101)
-        auto to_Y = [&](auto rt_, auto c_, const float4v& acc) {
+        auto to_Y = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
             constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-            store_act<C, rt>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
+            store_act<C, rt, decltype(h_)::value>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
         };
-        auto to_X = [&](auto rt_, auto c_, const float4v& acc) {
+        auto to_X = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
             constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-            store_act<C, rt>(acc, Xh[rt / 2][c], Xl[rt / 2][c]);
+            store_act<C, rt, decltype(h_)::value>(acc, Xh[rt / 2][c], Xl[rt / 2][c]);
         };
         constexpr int FN = Map::F_NERF;
         dense_layer<C, FN + L::frag0(0), 2, 16, L::bias0(0)>(ws, nerf_bias, pe_h, pe_l, to_Y);
@@ -287,9 +287,10 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) styled_rays_kernel(StyledAr
         }
         dense_layer<C, FN + L::frag0(6), 8, 16, L::bias0(6)>(ws, nerf_bias, Xh, Xl, to_Y);
         dense_layer<C, FN + L::frag0(7), 8, 16, L::bias0(7)>(ws, nerf_bias, Yh, Yl, to_X);
-        dense_layer<C, FN + L::frag0(8), 8, 1, L::bias0(8)>(ws, nerf_bias, Xh, Xl, [&](auto, auto c_, const float4v& acc) {
+        dense_layer<C, FN + L::frag0(8), 8, 1, L::bias0(8)>(ws, nerf_bias, Xh, Xl, [&](auto, auto c_, auto h_, const float4v& acc) {
             constexpr int c = decltype(c_)::value;
-            if (g == 0 && a.sigma && sidx[c] < a.M) a.sigma[sidx[c]] = acc[0];
+            if constexpr (decltype(h_)::value == 0)
+                if (g == 0 && a.sigma && sidx[c] < a.M) a.sigma[sidx[c]] = acc[0];
         });
         dense_layer<C, FN + L::frag0(9), 8, 16, L::bias0(9)>(ws, nerf_bias, Xh, Xl, to_Y);  // base_remap -> Y
         ws.template skip<FN + kTrunkFrags, Map::GAP>();
@@ -307,20 +308,20 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) styled_rays_kernel(StyledAr
             append<C>(Bh, Bl, 18, zb_h, zb_l);
             half8 Th[NCT], Tl[NCT];
             dense_layer<C, Map::F_STYLE + style_frag0(0), 19, 16, kConcatBiasFloats + style_bias0(0)>(
-                ws, pair_bias, Bh, Bl, [&](auto rt_, auto c_, const float4v& acc) {
-                    constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-                    store_act<C, rt>(acc, Th[c], Tl[c]);
-                    if constexpr (rt & 1) stash_store<C>(slab, tid, rt / 2, c, Th[c], Tl[c]);
+                ws, pair_bias, Bh, Bl, [&](auto rt_, auto c_, auto h_, const float4v& acc) {
+                    constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value, hf = decltype(h_)::value;
+                    store_act<C, rt, hf>(acc, Th[c], Tl[c]);
+                    if constexpr ((rt & 1) && hf == 1) stash_store<C>(slab, tid, rt / 2, c, Th[c], Tl[c]);
                 });
         }
         stash_load<C>(slab, tid, Xh, Xl);
         // ---- style layers 1..7 -> rgb (models.py:172-179)
         style_tail<C, Map::F_STYLE, kConcatBiasFloats>(ws, pair_bias, pe_h, pe_l, zb_h, zb_l, Xh, Xl, Yh, Yl,
-                                                       [&](auto c_, const float4v& acc) {
-                                                           constexpr int c = decltype(c_)::value;
+                                                       [&](auto c_, auto h_, const float4v& acc) {
+                                                           constexpr int c = decltype(c_)::value, hf = decltype(h_)::value;
                                                            if (g == 0 && a.rgb && sidx[c] < a.M) {
 #pragma unroll
-                                                               for (int r = 0; r < 3; ++r)
+                                                               for (int r = 2 * hf; r < (hf ? 3 : 2); ++r)
                                                                    a.rgb[sidx[c] * 3 + r] = 1.0f / (1.0f + expf(-acc[r]));
                                                            }
                                                        });
@@ -370,13 +371,13 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) concat_kernel(ConcatArgs a)
     half8 Xh[8][NCT], Xl[8][NCT], Yh[8][NCT], Yl[8][NCT];
     // layers 0..3 through the shared helper would also run layer 4 into registers; the granular op wants
     // the fp32 outputs of layer 4, so it is spelled out here
-    auto to_Y = [&](auto rt_, auto c_, const float4v& acc) {
+    auto to_Y = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
         constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-        store_act<C, rt>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
+        store_act<C, rt, decltype(h_)::value>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
     };
-    auto to_X = [&](auto rt_, auto c_, const float4v& acc) {
+    auto to_X = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
         constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-        store_act<C, rt>(acc, Xh[rt / 2][c], Xl[rt / 2][c]);
+        store_act<C, rt, decltype(h_)::value>(acc, Xh[rt / 2][c], Xl[rt / 2][c]);
     };
     {
         half8 Bh[3][NCT], Bl[3][NCT];
@@ -403,13 +404,11 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) concat_kernel(ConcatArgs a)
         append<C>(Bh, Bl, 8, z_h, z_l);
         append<C>(Bh, Bl, 9, pe_h[0], pe_l[0]);
         append<C>(Bh, Bl, 10, pe_h[1], pe_l[1]);
-        dense_layer<C, concat_frag0(4), 11, 16, 256 * 4>(ws, bias_lane, Bh, Bl, [&](auto rt_, auto c_, const float4v& acc) {
-            constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
+        dense_layer<C, concat_frag0(4), 11, 16, 256 * 4>(ws, bias_lane, Bh, Bl, [&](auto rt_, auto c_, auto h_, const float4v& acc) {
+            constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value, hf = decltype(h_)::value;
             if (sidx[c] < a.M) {
-                float4v v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = relu(acc[r]);
-                *reinterpret_cast<float4v*>(a.out + sidx[c] * 256 + 16 * rt + 4 * g) = v;
+                float* o = a.out + sidx[c] * 256 + 16 * rt + 4 * g + 2 * hf;
+                o[0] = relu(acc[2 * hf]), o[1] = relu(acc[2 * hf + 1]);
             }
         });
     }
@@ -473,15 +472,15 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) style_kernel(StyleArgs a) {
     append<C>(Bh, Bl, 17, pe_h[1], pe_l[1]);
     append<C>(Bh, Bl, 18, z_h, z_l);
     dense_layer<C, style_frag0(0), 19, 16, kConcatBiasFloats + style_bias0(0)>(
-        ws, bias_lane, Bh, Bl, [&](auto rt_, auto c_, const float4v& acc) {
+        ws, bias_lane, Bh, Bl, [&](auto rt_, auto c_, auto h_, const float4v& acc) {
             constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-            store_act<C, rt>(acc, Xh[rt / 2][c], Xl[rt / 2][c]);
+            store_act<C, rt, decltype(h_)::value>(acc, Xh[rt / 2][c], Xl[rt / 2][c]);
         });
-    style_tail<C, 0, kConcatBiasFloats>(ws, bias_lane, pe_h, pe_l, z_h, z_l, Xh, Xl, Yh, Yl, [&](auto c_, const float4v& acc) {
-        constexpr int c = decltype(c_)::value;
+    style_tail<C, 0, kConcatBiasFloats>(ws, bias_lane, pe_h, pe_l, z_h, z_l, Xh, Xl, Yh, Yl, [&](auto c_, auto h_, const float4v& acc) {
+        constexpr int c = decltype(c_)::value, hf = decltype(h_)::value;
         if (g == 0 && sidx[c] < a.M) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) a.rgb[sidx[c] * 3 + r] = 1.0f / (1.0f + expf(-acc[r]));
+            for (int r = 2 * hf; r < (hf ? 3 : 2); ++r) a.rgb[sidx[c] * 3 + r] = 1.0f / (1.0f + expf(-acc[r]));
         }
     });
 }

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libtgtc_hip.so")
+LIB_PATH = os.environ.get("TGTC_LIB") or os.path.join(_HERE, "csrc", "libtgtc_hip.so")   # TGTC_LIB: development builds
 
 PREC_FP16X3 = 0   # split-fp16, fp32-equivalent (parity mode)
 PREC_FP16 = 1     # single fp16 MFMA product (fast mode)
@@ -44,6 +44,7 @@ _SIGNATURES = {
     "tgtc_nerf_mlp_forward": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
     "tgtc_nerf_forward_rays": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p],
     "tgtc_time_next_nerf_launch": [c_int, c_void_p, c_void_p],
+    "tgtc_debug_set_stamps": [c_void_p],
     "tgtc_composite": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "tgtc_sample_fine": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "tgtc_render_workspace_bytes": [c_int64, c_int, c_int],
