@@ -87,6 +87,36 @@ def cpu_baseline(n_rays, chunk=1024):
                       "torch %s CPU fp32, %d threads, %.1f s" % (n_rays, chunk, torch.__version__, cores, dt)}
 
 
+def bench_style2d(args):
+    """Config 3's per-frame 2-D pass at 400x400: patch-embed both images, transformer, CNN decoder, resize, style
+    feature, plus one VGG encode (what train-time consumers read).  Prints ms/frame."""
+    from tgtc_style_amd import style2d, synth
+    mods = {}
+    for name, cls, sd in (("tr", style2d.Transformer, synth.transformer_state(5)), ("pe", style2d.PatchEmbed, synth.embed_state(6)),
+                          ("dec", style2d.Decoder, synth.decoder_state(7)), ("vgg", style2d.VGG, synth.vgg_state(8))):
+        m = cls()
+        m.load_state_dict(t_state(sd))
+        m.precision = args.precision
+        mods[name] = m.cuda()
+    net = style2d.StyTrans(mods["vgg"], mods["dec"], mods["pe"], mods["tr"])
+    content = torch.rand(1, 3, H, W, device="cuda")
+    style = torch.from_numpy(synth.style_image(11, H, W)).cuda()
+    times = {}
+    for label, fn in (("stylize (embed x2 + transformer + decoder + resize + feature)", lambda: style2d.stylize_frame(net, content, style)),
+                      ("vgg encode_with_intermediate", lambda: net.encode_with_intermediate(content))):
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        torch.cuda.synchronize()
+        times[label] = (time.perf_counter() - t0) / args.steps * 1e3
+    print(json.dumps({"metric": "ms/frame, 2-D style pass at 400x400 (2500 tokens)", "value": sum(times.values()),
+                      "unit": "ms", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": False,
+                      "dtype": args.precision, "data": "synthetic", "parts_ms": times}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +124,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="fp16x3", choices=["fp16x3", "fp16"])
     ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the CPU baseline sample (0 disables)")
+    ap.add_argument("--workload", default="plain", choices=["plain", "styled", "style2d"],
+                    help="plain = BASELINE config 2 (the headline); styled = config 3's ray path (concat + style MLPs); "
+                         "style2d = config 3's per-frame ViT + CNN decoder + VGG pass (reports ms/frame)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,8 +142,19 @@ def main():
 
     from tgtc_style_amd import hip, rendering, synth, utils
     lib = hip.load()
+    if args.workload == "style2d":
+        return bench_style2d(args)
     coarse, fine = build_nets(args.precision)
     renderer = rendering.RayRenderer(coarse, fine)
+    z = None
+    if args.workload == "styled":
+        from tgtc_style_amd import models
+        a = type("A", (NetArgs,), {"precision": args.precision, "style_D": 8, "vae_latent": 32})
+        cm, sm = models.StyleMLP_before_concat(a), models.StyleMLP_Wild_multilayers(a)
+        cm.load_state_dict(t_state(synth.concat_state(2)))
+        sm.load_state_dict(t_state(synth.style_state(3)))
+        renderer = rendering.RayRenderer(coarse, fine, models.StylePair(cm.cuda(), sm.cuda()))
+        z = torch.from_numpy(np.random.default_rng(4).standard_normal((H * W, 32)).astype(np.float32)).cuda()
     focal = synth.fern_intrinsics(H, W)
     n_rays = H * W
     image = torch.empty(n_rays, 4, device="cuda", dtype=torch.float32)
@@ -125,7 +169,7 @@ def main():
         o, d = utils.gen_rays(H, W, focal, pose)
         if timed_idx is not None:
             hip.check(lib.tgtc_time_next_nerf_launch(1, ev[timed_idx][0].cuda_event, ev[timed_idx][1].cuda_event))
-        out = renderer.render(o, d, N_COARSE, N_FINE, near=0., far=1.)
+        out = renderer.render(o, d, N_COARSE, N_FINE, near=0., far=1., z=z)
         image[:, :3] = out["rgb"]
         image[:, 3] = out["t"]
         if world > 1:
@@ -150,8 +194,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     assert bool(torch.isfinite(image).all())
+    if args.workload == "styled":
+        if rank == 0:
+            flop_ray = 2 * (N_COARSE * MAC_SIGMA + (N_COARSE + N_FINE) * 1506912)     # 704.4 MFLOP/ray
+            print(json.dumps({"metric": "rays/sec (128c+64f samples) on fern 400x400, stylised (concat + style MLPs)",
+                              "value": world * n_rays * args.steps / dt, "unit": "rays/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+                              "dtype": args.precision, "config": {"workload": "fern 400x400 stylised render, 128c+64f",
+                                                                  "algorithmic_mflop_per_ray": flop_ray / 1e6},
+                              "whole_path_tflops": world * n_rays * args.steps / dt * flop_ray / 1e12}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     if rank == 0:
         rays_total = world * n_rays * args.steps

@@ -30,7 +30,7 @@ struct NerfLayout {
     static constexpr int kBiasFloats = nerf_bias0(12);  // 2464
 };
 
-constexpr int kNerfBiasBytes = 12288;  // 2464 floats padded to a multiple of 4 KiB (4 waves x 1 KiB LDS-DMA)
+constexpr int kNerfBiasBytes = 16384;  // 2464 floats padded to a multiple of 8 KiB (up to 8 waves x 1 KiB LDS-DMA)
 static_assert(NerfLayout::kBiasFloats * 4 <= kNerfBiasBytes, "bias table");
 static_assert(NerfLayout::kFragsFull == 1172, "fragment count");
 

@@ -34,14 +34,14 @@ struct NerfArgs {
 };
 
 template <class C, int IN_MODE, bool FULL>
-__global__ void __launch_bounds__(C::NWAVES * 64, 1) nerf_mlp_kernel(NerfArgs a) {
+__global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES * C::WG_PER_CU / 4) nerf_mlp_kernel(NerfArgs a) {
     constexpr int NCT = C::NCT;
     constexpr bool SPLIT = C::SPLIT;
     constexpr int NFRAG = FULL ? NerfLayout::kFragsFull : NerfLayout::kFragsSigma;
     using L = NerfLayout;
 
     // ALL LDS in one array (a second __shared__ object makes hipcc drain vmcnt before LDS reads).
-    __shared__ __attribute__((aligned(16))) char smem[kRingBytes + kNerfBiasBytes];
+    __shared__ __attribute__((aligned(16))) char smem[C::RING_BYTES + kNerfBiasBytes];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) nerf_mlp_kernel(NerfArgs a)
 #pragma unroll
     for (int j = 0; j < kNerfBiasBytes / (C::NWAVES * 1024); ++j)
         __builtin_amdgcn_global_load_lds(TGTC_GPTR(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16),
-                                         TGTC_LPTR(smem + kRingBytes + (j * C::NWAVES + wave) * 1024), 16, 0, 0);
+                                         TGTC_LPTR(smem + C::RING_BYTES + (j * C::NWAVES + wave) * 1024), 16, 0, 0);
     stamp(1);
     ws.prologue();
 
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(C::NWAVES * 64, 1) nerf_mlp_kernel(NerfArgs a)
         }
     }
 
-    const lds_cptr bias_lane = opaque((lds_cptr)smem + kRingBytes + 16 * g);
+    const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * g);
     stamp(2);
     ws.start();
     stamp(3);
@@ -240,8 +240,12 @@ static int launch_nerf(const NerfArgs& a, hipStream_t st) {
     return TGTC_OK;
 }
 
-using CfgFast = MlpCfg<4, 4, false>;
-using CfgExact = MlpCfg<4, 2, true>;
+// Geometry chosen by measurement (tools/bench_variants.sh, profiles/r1_kernel_variants.md): 8 waves per
+// workgroup = 2 per SIMD, every MFMA operand in arch VGPRs (<= 256 registers per wave).  MFMAs whose B
+// operand sits in the accumulator half of the register file issue ~25 % slower (tools/microbench/mfma_regs),
+// which is what the 4-wave / 4-column-tile geometry (470-510 registers) ran into.
+using CfgFast = MlpCfg<8, 2, false, 4>;
+using CfgExact = MlpCfg<8, 1, true, 4>;
 
 template <int IN_MODE, bool FULL>
 static int dispatch_nerf(const tgtc_net* net, NerfArgs& a, hipStream_t st) {
@@ -250,7 +254,8 @@ static int dispatch_nerf(const tgtc_net* net, NerfArgs& a, hipStream_t st) {
     a.stamps = g_stamps;
 #ifdef TGTC_DEV_VARIANT   // development builds: only the hot-path kernels of one experimental configuration
     if constexpr (IN_MODE == IN_RAYS) {
-        if (net->precision == TGTC_PREC_FP16) return launch_nerf<TGTC_DEV_VARIANT, IN_MODE, FULL>(a, st);
+        if (net->precision == (TGTC_DEV_VARIANT::SPLIT ? TGTC_PREC_FP16X3 : TGTC_PREC_FP16))
+            return launch_nerf<TGTC_DEV_VARIANT, IN_MODE, FULL>(a, st);
     }
     return fail(TGTC_ERR_UNSUPPORTED, "development build: kernel not compiled");
 #else

@@ -179,7 +179,7 @@ __device__ __forceinline__ void splat8(float v, half8& hi, half8& lo) {
 
 // ------------------------------------------------------------------------------------------------ fused
 template <class C>
-__global__ void __launch_bounds__(C::NWAVES * 64, 1) styled_rays_kernel(StyledArgs a) {
+__global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES / 4) styled_rays_kernel(StyledArgs a) {
     constexpr int NCT = C::NCT;
     constexpr bool SPLIT = C::SPLIT;
     using Map = StyledMap<C>;
@@ -339,7 +339,7 @@ struct ConcatArgs {
 };
 
 template <class C>
-__global__ void __launch_bounds__(C::NWAVES * 64, 1) concat_kernel(ConcatArgs a) {
+__global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES / 4) concat_kernel(ConcatArgs a) {
     constexpr int NCT = C::NCT;
     constexpr bool SPLIT = C::SPLIT;
     __shared__ __attribute__((aligned(16))) char smem[kRingBytes + kStylePairBiasBytes];
@@ -425,7 +425,7 @@ struct StyleArgs {
 };
 
 template <class C>
-__global__ void __launch_bounds__(C::NWAVES * 64, 1) style_kernel(StyleArgs a) {
+__global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES / 4) style_kernel(StyleArgs a) {
     constexpr int NCT = C::NCT;
     constexpr bool SPLIT = C::SPLIT;
     __shared__ __attribute__((aligned(16))) char smem[kRingBytes + kStylePairBiasBytes];
@@ -511,10 +511,10 @@ static std::vector<LayerSpec> style_specs(const tgtc_linear* l) {
     return v;
 }
 
-using CfgFast = MlpCfg<4, 4, false>;
-using CfgExact = MlpCfg<4, 2, true>;
-using CfgFastNarrow = MlpCfg<4, 2, false>;   // granular style MLP: 512 extra input features live in registers
-using CfgExactNarrow = MlpCfg<4, 1, true>;
+using CfgFast = MlpCfg<8, 2, false, 4>;      // same geometry as the NeRF kernels (mlp_nerf.hip)
+using CfgExact = MlpCfg<8, 1, true, 4>;
+using CfgFastNarrow = MlpCfg<4, 2, false, 4>;   // granular style MLP: 512 extra input features live in registers
+using CfgExactNarrow = MlpCfg<4, 1, true, 4>;
 
 int styled_forward_rays_impl(const tgtc_net* nerf, const tgtc_net* style, const double* rays_o, const double* rays_d,
                              const float* ts, const float* z, int64_t R, int N, float* rgb, float* sigma,
@@ -530,11 +530,11 @@ int styled_forward_rays_impl(const tgtc_net* nerf, const tgtc_net* style, const 
     if (nerf->precision == TGTC_PREC_FP16) {
         const long long tiles = (a.M + CfgFast::SAMPLES_PER_WG - 1) / CfgFast::SAMPLES_PER_WG;
         const unsigned grid = (unsigned)(tiles < style->n_wg ? tiles : style->n_wg);
-        styled_rays_kernel<CfgFast><<<grid, 256, 0, st>>>(a);
+        styled_rays_kernel<CfgFast><<<grid, CfgFast::NWAVES * 64, 0, st>>>(a);
     } else {
         const long long tiles = (a.M + CfgExact::SAMPLES_PER_WG - 1) / CfgExact::SAMPLES_PER_WG;
         const unsigned grid = (unsigned)(tiles < style->n_wg ? tiles : style->n_wg);
-        styled_rays_kernel<CfgExact><<<grid, 256, 0, st>>>(a);
+        styled_rays_kernel<CfgExact><<<grid, CfgExact::NWAVES * 64, 0, st>>>(a);
     }
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;
@@ -619,9 +619,9 @@ extern "C" int tgtc_concat_mlp_forward(const tgtc_net* style, const float* x, co
     TGTC_REQUIRE(x && latent && concat_features, "concat_mlp_forward: null pointer");
     ConcatArgs a{style->dev, style->dev + style->bias_bytes, M, x, latent, concat_features};
     if (style->precision == TGTC_PREC_FP16)
-        concat_kernel<CfgFast><<<(unsigned)((M + CfgFast::SAMPLES_PER_WG - 1) / CfgFast::SAMPLES_PER_WG), 256, 0, as_stream(stream)>>>(a);
+        concat_kernel<CfgFast><<<(unsigned)((M + CfgFast::SAMPLES_PER_WG - 1) / CfgFast::SAMPLES_PER_WG), CfgFast::NWAVES * 64, 0, as_stream(stream)>>>(a);
     else
-        concat_kernel<CfgExact><<<(unsigned)((M + CfgExact::SAMPLES_PER_WG - 1) / CfgExact::SAMPLES_PER_WG), 256, 0, as_stream(stream)>>>(a);
+        concat_kernel<CfgExact><<<(unsigned)((M + CfgExact::SAMPLES_PER_WG - 1) / CfgExact::SAMPLES_PER_WG), CfgExact::NWAVES * 64, 0, as_stream(stream)>>>(a);
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;
 }

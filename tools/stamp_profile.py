@@ -12,6 +12,8 @@ import bench  # noqa: E402
 from tgtc_style_amd import hip, synth, utils  # noqa: E402
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "fp16"
+NW = int(sys.argv[2]) if len(sys.argv) > 2 else 4      # waves per workgroup of the library under test
+NCT = int(sys.argv[3]) if len(sys.argv) > 3 else (4 if prec == "fp16" else 2)
 lib = hip.load()
 coarse, fine = bench.build_nets(prec)
 H = W = 400
@@ -20,21 +22,21 @@ R, N = H * W, 192
 ts = torch.sort(torch.rand(R, N, device="cuda"), -1)[0]
 rgb = torch.empty(R, N, 3, device="cuda")
 sig = torch.empty(R, N, device="cuda")
-stamps = torch.zeros(64 * 4 * 32, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(64 * NW * 32, dtype=torch.int64, device="cuda")
 for it in range(3):
     hip.check(lib.tgtc_debug_set_stamps(hip.ptr(stamps) if it == 2 else None))
     hip.check(lib.tgtc_nerf_forward_rays(fine.packed().handle, hip.ptr(o), hip.ptr(d), hip.ptr(ts), R, N, hip.ptr(rgb),
                                          hip.ptr(sig), hip.stream()))
 torch.cuda.synchronize()
 hip.check(lib.tgtc_debug_set_stamps(None))
-s = stamps.cpu().numpy().reshape(64, 4, 32)[:, :, :14].astype(np.float64)
+s = stamps.cpu().numpy().reshape(64, NW, 32)[:, :, :14].astype(np.float64)
 names = ["inputs", "glds issue", "posenc", "ring start", "L0", "L1", "L2", "L3", "L4", "L5(skip)", "L6", "L7",
          "sigma", "remap+rgb"]
 dt = np.diff(s, axis=2)            # [64,4,13]
 med = np.median(dt.reshape(-1, 13), 0)
 tot = np.median(s[:, :, 13] - s[:, :, 0])
 frags = [0, 0, 0, 0, 32, 128, 128, 128, 128, 160, 128, 128, 8, 204]
-per = 4 * 16 if prec == "fp16" else 6 * 16
+per = NCT * 16 * (1 if prec == "fp16" else 3)
 print("precision", prec, "median wave lifetime (stamped part): %.0f cycles" % tot)
 for i in range(13):
     ideal = frags[i + 1] * per
