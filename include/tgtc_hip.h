@@ -99,7 +99,7 @@ int tgtc_nerf_forward_rays(const tgtc_net* net, const double* rays_o, const doub
 int tgtc_time_next_nerf_launch(int full, void* start_event, void* stop_event);
 
 /* Diagnostics: while buf != NULL, the first 64 workgroups of every fused NeRF launch of the calling thread write
- * s_memtime stamps of their phase boundaries into buf ([64][4 waves][32] uint64).  Never set in production. */
+ * s_memtime stamps of their phase boundaries into buf ([64][8 waves][32] uint64).  Never set in production. */
 int tgtc_debug_set_stamps(void* buf);
 
 /* ------------------------------------------------------------------ a6: alpha compositing

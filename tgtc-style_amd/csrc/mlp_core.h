@@ -138,9 +138,13 @@ struct WeightStream {
         if constexpr (CH < NCHUNK) {
             constexpr int seg = seg_of(CH);
             constexpr size_t off = (size_t)(CH - Map::chunk0(seg)) * kChunkBytes;
+            // launder the base: inside a persistent tile loop every chunk address is loop invariant, and hipcc
+            // would otherwise hoist hundreds of 64-bit per-lane addresses into the pre-header and spill them
+            const char* base = src[seg];
+            asm volatile("" : "+v"(base));
 #pragma unroll
             for (int j = 0; j < C::GPC; ++j)
-                __builtin_amdgcn_global_load_lds(TGTC_GPTR(src[seg] + off + j * 1024),
+                __builtin_amdgcn_global_load_lds(TGTC_GPTR(base + off + j * 1024),
                                                  TGTC_LPTR(lds_wave + (CH % C::SLOTS) * kChunkBytes + j * 1024),
                                                  16, 0, 0);
         }

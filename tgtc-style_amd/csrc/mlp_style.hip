@@ -61,21 +61,29 @@ __device__ __forceinline__ void append(half8 (&Bh)[KSN][C::NCT], half8 (&Bl)[KSN
     for (int c = 0; c < C::NCT; ++c) Bh[at][c] = h[c], Bl[at][c] = l[c];
 }
 
+// The slab pointer handed to these helpers is the lane's own (slab + tid*16), laundered through an empty asm
+// at every use: the slab addresses are invariant across the persistent tile loop, and without this hipcc hoists
+// all 2 x 32 address pairs out of the loop and spills hundreds of registers to keep them alive.
+__device__ __forceinline__ char* launder(char* p) {
+    asm volatile("" : "+v"(p));
+    return p;
+}
 template <class C>
-__device__ __forceinline__ void stash_store(char* slab, int tid, int ks, int c, half8 h, half8 l) {
+__device__ __forceinline__ void stash_store(char* lane_slab, int ks, int c, half8 h, half8 l) {
     constexpr int P = C::SPLIT ? 2 : 1;
-    half8* p = reinterpret_cast<half8*>(slab) + (size_t)((ks * C::NCT + c) * P) * (C::NWAVES * 64) + tid;
+    half8* p = reinterpret_cast<half8*>(launder(lane_slab)) + (size_t)((ks * C::NCT + c) * P) * (C::NWAVES * 64);
     p[0] = h;
     if constexpr (C::SPLIT) p[C::NWAVES * 64] = l;
 }
 template <class C>
-__device__ __forceinline__ void stash_load(const char* slab, int tid, half8 (&Ah)[8][C::NCT], half8 (&Al)[8][C::NCT]) {
+__device__ __forceinline__ void stash_load(char* lane_slab, half8 (&Ah)[8][C::NCT], half8 (&Al)[8][C::NCT]) {
     constexpr int P = C::SPLIT ? 2 : 1;
+    const half8* base = reinterpret_cast<const half8*>(launder(lane_slab));
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
         for (int c = 0; c < C::NCT; ++c) {
-            const half8* p = reinterpret_cast<const half8*>(slab) + (size_t)((ks * C::NCT + c) * P) * (C::NWAVES * 64) + tid;
+            const half8* p = base + (size_t)((ks * C::NCT + c) * P) * (C::NWAVES * 64);
             Ah[ks][c] = p[0];
             if constexpr (C::SPLIT) Al[ks][c] = p[C::NWAVES * 64];
         }
@@ -190,7 +198,7 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES / 4) styled_rays_ker
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, n = lane & 15;
-    char* slab = a.stash + (size_t)blockIdx.x * kStashBytesPerWG;
+    char* slab = a.stash + (size_t)blockIdx.x * kStashBytesPerWG + (size_t)tid * 16;   // this lane's 16-byte column
 
     WeightStream<C, Map> ws;
     const char* const streams[3] = {a.concat_stream, a.nerf_stream, a.style_stream};
@@ -260,7 +268,7 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES / 4) styled_rays_ker
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) stash_store<C>(slab, tid, ks, c, Yh[ks][c], Yl[ks][c]);
+            for (int c = 0; c < NCT; ++c) stash_store<C>(slab, ks, c, Yh[ks][c], Yl[ks][c]);
 
         // ---- NeRF trunk (models.py:95-101)
         auto to_Y = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
@@ -296,7 +304,7 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES / 4) styled_rays_ker
         ws.template skip<FN + kTrunkFrags, Map::GAP>();
 
         // ---- style layer 0 on [remap (Y) | concat_features (slab -> X) | pe | mean z]; outputs stream to the slab
-        stash_load<C>(slab, tid, Xh, Xl);
+        stash_load<C>(slab, Xh, Xl);
         {
             half8 Bh[19][NCT], Bl[19][NCT];
 #pragma unroll
@@ -311,10 +319,10 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES / 4) styled_rays_ker
                 ws, pair_bias, Bh, Bl, [&](auto rt_, auto c_, auto h_, const float4v& acc) {
                     constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value, hf = decltype(h_)::value;
                     store_act<C, rt, hf>(acc, Th[c], Tl[c]);
-                    if constexpr ((rt & 1) && hf == 1) stash_store<C>(slab, tid, rt / 2, c, Th[c], Tl[c]);
+                    if constexpr ((rt & 1) && hf == 1) stash_store<C>(slab, rt / 2, c, Th[c], Tl[c]);
                 });
         }
-        stash_load<C>(slab, tid, Xh, Xl);
+        stash_load<C>(slab, Xh, Xl);
         // ---- style layers 1..7 -> rgb (models.py:172-179)
         style_tail<C, Map::F_STYLE, kConcatBiasFloats>(ws, pair_bias, pe_h, pe_l, zb_h, zb_l, Xh, Xl, Yh, Yl,
                                                        [&](auto c_, auto h_, const float4v& acc) {
@@ -527,14 +535,19 @@ int styled_forward_rays_impl(const tgtc_net* nerf, const tgtc_net* style, const 
     a.style_stream = style->dev + style->stream2_off, a.stash = style->dev + style->stash_off;
     a.M = R * (int64_t)N, a.N = N, a.rays_o = rays_o, a.rays_d = rays_d, a.ts = ts, a.z = z, a.rgb = rgb, a.sigma = sigma;
     if (a.M >= 0x7fffffffLL) return fail(TGTC_ERR_UNSUPPORTED, "styled_forward_rays: too many samples in one launch");
+#ifdef TGTC_DEV_STYLED_FAST_ONLY
+    if (nerf->precision != TGTC_PREC_FP16) return fail(TGTC_ERR_UNSUPPORTED, "development build");
+#endif
     if (nerf->precision == TGTC_PREC_FP16) {
         const long long tiles = (a.M + CfgFast::SAMPLES_PER_WG - 1) / CfgFast::SAMPLES_PER_WG;
         const unsigned grid = (unsigned)(tiles < style->n_wg ? tiles : style->n_wg);
         styled_rays_kernel<CfgFast><<<grid, CfgFast::NWAVES * 64, 0, st>>>(a);
     } else {
+#ifndef TGTC_DEV_STYLED_FAST_ONLY
         const long long tiles = (a.M + CfgExact::SAMPLES_PER_WG - 1) / CfgExact::SAMPLES_PER_WG;
         const unsigned grid = (unsigned)(tiles < style->n_wg ? tiles : style->n_wg);
         styled_rays_kernel<CfgExact><<<grid, CfgExact::NWAVES * 64, 0, st>>>(a);
+#endif
     }
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;
@@ -612,6 +625,7 @@ extern "C" int tgtc_style_create(const tgtc_linear* concat_layers, int n_concat,
     return TGTC_OK;
 }
 
+#ifndef TGTC_DEV_STYLED_FAST_ONLY
 extern "C" int tgtc_concat_mlp_forward(const tgtc_net* style, const float* x, const float* latent, int64_t M,
                                        float* concat_features, void* stream) {
     TGTC_REQUIRE(style && style->kind == 1 && M >= 0, "concat_mlp_forward: bad argument");
@@ -639,6 +653,8 @@ extern "C" int tgtc_style_mlp_forward(const tgtc_net* style, const float* x, con
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;
 }
+
+#endif  // TGTC_DEV_STYLED_FAST_ONLY
 
 extern "C" int tgtc_styled_forward_rays(const tgtc_net* nerf, const tgtc_net* style, const double* rays_o,
                                         const double* rays_d, const float* ts, const float* z, int64_t R, int N,

@@ -12,8 +12,8 @@ import bench  # noqa: E402
 from tgtc_style_amd import hip, synth, utils  # noqa: E402
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "fp16"
-NW = int(sys.argv[2]) if len(sys.argv) > 2 else 4      # waves per workgroup of the library under test
-NCT = int(sys.argv[3]) if len(sys.argv) > 3 else (4 if prec == "fp16" else 2)
+NW = int(sys.argv[2]) if len(sys.argv) > 2 else 8      # waves per workgroup of the library under test
+NCT = int(sys.argv[3]) if len(sys.argv) > 3 else (2 if prec == "fp16" else 1)
 lib = hip.load()
 coarse, fine = bench.build_nets(prec)
 H = W = 400
