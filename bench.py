@@ -37,7 +37,7 @@ PEAK_FP16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
 # HBM bytes of one fine-pass launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
 # WRITE_SIZE collected in separate --pmc runs; FETCH_SIZE calibrated 1:1 on the known 4-B-per-lane depth reads
 # of this kernel, see profiles/r1_pmc_summary.md).  bench.py cannot collect counters itself.
-PMC_TRAFFIC_BYTES = {"fp16x3": (119542.14 + 480000.0) * 1024, "fp16": None}
+PMC_TRAFFIC_BYTES = {"fp16x3": (100130.0 + 480000.0) * 1024, "fp16": None}
 
 
 class NetArgs:
@@ -135,11 +135,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    # one rank per GPU; TGTC_DIST_BACKEND=gloo lets several ranks share one GPU for functional rehearsals of the N>1 path
+    backend = os.environ.get("TGTC_DIST_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     if args.workload == "style2d":
         return bench_style2d(args)
@@ -193,7 +199,10 @@ def run_rays(args, precision, rank, world, dist):
         image[:, :3] = out["rgb"]
         image[:, 3] = out["t"]
         if world > 1:
-            dist.all_gather_into_tensor(gathered, image)
+            if dist.get_backend() == "nccl":
+                dist.all_gather_into_tensor(gathered, image)     # RCCL over xGMI: [160000,4] fp32 per rank
+            else:
+                dist.all_gather(list(gathered.chunk(world)), image)
 
     for i in range(args.warmup):
         step(i)
