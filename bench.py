@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="fp16x3", choices=["fp16x3", "fp16"])
+    ap.add_argument("--precision", default="fp16x3", choices=["fp16x3", "fp16", "fp16mx"])
     ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the CPU baseline sample (0 disables)")
     ap.add_argument("--alt-precision", default="fp16", help="second precision reported under `alt_precision` ('' disables)")
     ap.add_argument("--workload", default="plain", choices=["plain", "styled", "style2d"],
@@ -241,7 +241,8 @@ def run_rays(args, precision, rank, world, dist):
         rays_total = world * n_rays * args.steps
         flop_launch = 2.0 * MAC_FULL * n_rays * (N_COARSE + N_FINE)      # algorithmic flop of one fine-pass launch
         achieved = flop_launch / (kernel_ms * 1e-3) / 1e12
-        mfma_per_product = 3 if precision == "fp16x3" else 1
+        # MFMA issue slots per algorithmic product: fp16mx = 4 f16 + 2 fp6 16x16x128 instructions per 128-deep block
+        mfma_per_product = {"fp16x3": 3.0, "fp16": 1.0, "fp16mx": 1.5}[precision]
         line = {
             "metric": "rays/sec (128c+64f samples) on fern 400x400",
             "value": rays_total / dt,
@@ -253,14 +254,15 @@ def run_rays(args, precision, rank, world, dist):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16 MFMA operands split hi+lo (3 products), f32 accumulate" if precision == "fp16x3"
-                     else "f16 MFMA operands, f32 accumulate",
+            "dtype": {"fp16x3": "f16 MFMA operands split hi+lo (3 products), f32 accumulate",
+                      "fp16": "f16 MFMA operands, f32 accumulate",
+                      "fp16mx": "f16 MFMA product + two block-scaled fp6 (e2m3) correction products, f32 accumulate"}[precision],
             "data": "synthetic",
             "config": {"workload": "fern-shaped 400x400 frame, plain NeRF render (style off), 128 coarse + 64 fine "
                                    "samples/ray, one whole frame per rank per step, seeded random-init weights",
                        "rays_per_step": world * n_rays, "precision": precision, "sharding": "frames",
                        "algorithmic_mflop_per_ray": FLOP_PER_RAY / 1e6},
-            "roofline": {"bound": "mfma", "kernel": "nerf_mlp_kernel<FULL> (fine pass: PE + 12 dense layers, %d samples)"
+            "roofline": {"bound": "mfma", "kernel": ("nerf_mx_kernel<FULL>" if precision == "fp16mx" else "nerf_mlp_kernel<FULL>") + " (fine pass: PE + 12 dense layers, %d samples)"
                                                    % (n_rays * (N_COARSE + N_FINE)),
                          "achieved": achieved, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP16_TFLOPS, "traffic": PMC_TRAFFIC_BYTES.get(precision),

@@ -37,6 +37,7 @@ extern "C" {
 /* Arithmetic mode of the fused MLP kernels (MFMA operands; accumulation is always fp32). */
 #define TGTC_PREC_FP16X3 0 /* split fp16 (hi+lo) x 3 MFMA products: fp32-equivalent, the parity mode */
 #define TGTC_PREC_FP16 1   /* single fp16 MFMA product: fastest, ~2e-3 abs error on composited RGB */
+#define TGTC_PREC_FP16_FP6 2 /* fp16 product + two block-scaled fp6 (e2m3) correction products: ~1e-4, NeRF nets only */
 
 typedef struct tgtc_net tgtc_net; /* opaque: packed weights of one network, resident in HBM */
 

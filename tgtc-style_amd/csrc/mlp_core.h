@@ -166,11 +166,15 @@ struct WeightStream {
             if constexpr (C::SPLIT) ql[(F / G) & 1][F % G] = read<F, 1>();
         }
     }
-    __device__ __forceinline__ void start() {
+    // wait for this wave's pieces of chunks 0 and 1, then the workgroup barrier that makes them visible
+    __device__ __forceinline__ void start_ring() const {
         constexpr int issued_last = (C::SLOTS - 1 < NCHUNK - 1) ? C::SLOTS - 1 : NCHUNK - 1;
         constexpr int need = NCHUNK > 1 ? 1 : 0;
         wait_vmcnt<(issued_last - need) * C::GPC>();
         __builtin_amdgcn_s_barrier();
+    }
+    __device__ __forceinline__ void start() {
+        start_ring();
         static_for<G>([&](auto f) { fetch<decltype(f)::value>(); });
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -1,0 +1,277 @@
+// TGTC_PREC_FP16_FP6: fp32-equivalent products from ONE fp16 MFMA pass plus two block-scaled fp6 passes.
+//
+//   W = Wh + Wl (Wh = fp16(W)),  a = Ah + Al (Ah = fp16(a));   W.a ~= Wh.Ah + Wl.Ah + Wh.Al
+//   main   Wh.Ah  on v_mfma_f32_16x16x32_f16                     (4 instructions per 128-deep k block)
+//   corr1  Wl.Ah  on v_mfma_scale_f32_16x16x128_f8f6f4 (e2m3)    (1 instruction: Wl6 from the stream, Ah6 from registers)
+//   corr2  Wh.Al  on the same instruction                        (1 instruction: Wh6 converted from Wh in registers, Al6)
+// Both correction terms are ~2^-11 of the main term, so their 4-bit (e2m3) operands leave a relative error of
+// ~2^-16 per product -- 30 x better than the single fp16 product -- at 6.15 MFMA issue slots per block instead
+// of the 12 of TGTC_PREC_FP16X3 (an fp6 16x16x128 costs about what an f16 16x16x32 costs, tools/microbench/mfma_fp6).
+// Block scales (E8M0, one per lane = per row/column and 32 k values): weights carry one exponent per output
+// row (table in LDS, filled by the packer); activations get theirs from the running maximum of the 32 values a
+// lane holds.  Lane maps (probed in tools/microbench/mfma_fp6_check.py): lane l holds row/column l&15 and the 32
+// consecutive k = 32(l>>4)+i, six bits each, little endian; code = e2m3(value / scale), RNE, saturating.
+// The 32 values a lane holds for four consecutive fp16 k-steps s (element j) are the SAME logical k values
+// (i = 8s+j), so Ah6 / Wh6 are one v_cvt_scalef32_pk32_fp6_f16 of registers that already exist.
+//
+// Positional-encoding / direction k-steps keep the three-product fp16 scheme (their B fragments do not come
+// out of an accumulator); NCT = 1 column tile per wave.
+#pragma once
+#include "mlp_core.h"
+
+namespace tgtc {
+
+typedef unsigned u6v __attribute__((ext_vector_type(6)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef int i8v __attribute__((ext_vector_type(8)));
+typedef _Float16 half32 __attribute__((ext_vector_type(32)));
+
+// ------------------------------------------------------------------------------------------------ stream layout
+// The stream is a sequence of GROUPS, one LDS->register burst each:
+//   K group (one 128-deep block of one row tile), 5632 B: [Wh k-step 0..3: 4 x 1 KiB, lane*16]
+//                                                         [Wl6 dwords 0-3: 1 KiB, lane*16][Wl6 dwords 4-5: 512 B, lane*8]
+//   P group (the PE / direction k-steps of one row tile), npe x 2 KiB: [hi, lo] per k-step, lane*16
+// Groups never straddle the end of the 128 KiB ring (padding inserted), they may straddle 16 KiB chunks.
+struct MxShape {
+    int rt, nkb, npe;
+};
+constexpr int kMxKGroupBytes = 5632;
+constexpr int kMxMaxGroups = 512;
+
+struct MxTable {
+    int n = 0;
+    int off[kMxMaxGroups] = {};
+    short npe[kMxMaxGroups] = {};  // 0: K group
+    int first[16] = {};            // first group of layer l; first[nl] = n
+    int bytes = 0;                 // stream length, chunk padded
+};
+
+template <int NL>
+constexpr MxTable mx_make_table(const MxShape (&s)[NL], int ring_bytes) {
+    MxTable t;
+    int off = 0;
+    for (int l = 0; l < NL; ++l) {
+        t.first[l] = t.n;
+        for (int rt = 0; rt < s[l].rt; ++rt) {
+            const int ng = s[l].nkb + (s[l].npe ? 1 : 0);
+            for (int q = 0; q < ng; ++q) {
+                const int npe = q < s[l].nkb ? 0 : s[l].npe;
+                const int size = npe ? npe * 2048 : kMxKGroupBytes;
+                if (off / ring_bytes != (off + size - 1) / ring_bytes) off = (off / ring_bytes + 1) * ring_bytes;
+                t.off[t.n] = off, t.npe[t.n] = (short)npe, ++t.n;
+                off += size;
+            }
+        }
+    }
+    t.first[NL] = t.n;
+    t.bytes = (off + kChunkBytes - 1) / kChunkBytes * kChunkBytes;
+    return t;
+}
+
+//   layer      L0  L1  L2  L3  L4  L5  L6  L7  SIG REMAP C0  C1      (mlp_layouts.h)
+constexpr MxShape kNerfMxShape[12] = {{16, 0, 2}, {16, 2, 0}, {16, 2, 0}, {16, 2, 0}, {16, 2, 0}, {16, 2, 2},
+                                      {16, 2, 0}, {16, 2, 0}, {1, 2, 0},  {16, 2, 0}, {8, 2, 1},  {1, 1, 0}};
+inline constexpr MxTable kNerfMxTable = mx_make_table(kNerfMxShape, kRingBytes);
+constexpr int kNerfMxScaleOff = 10240;  // byte offset of the row-exponent table inside the bias region (u16 per row)
+
+// e2m3: 1 sign, 2 exponent (bias 1), 3 mantissa bits; codes are monotone in magnitude
+__host__ __device__ inline float e2m3_value(int code) {
+    const int e = (code >> 3) & 3, m = code & 7;
+    const float v = e == 0 ? m * 0.125f : (1.0f + m * 0.125f) * (float)(1 << (e - 1));
+    return (code & 32) ? -v : v;
+}
+
+// ------------------------------------------------------------------------------------------------ device side
+template <class C, class Map, const MxTable& T>
+struct MxReader {
+    using Ring = WeightStream<C, Map>;
+    struct Slot {
+        half8 u[5];
+        u2v up;
+    };
+    Ring ring;
+    lds_cptr b16_lo, b16_hi, b8_lo, b8_hi;  // ring + lane*16 / lane*8, lower / upper 64 KiB
+    Slot q[2];
+
+    __device__ __forceinline__ void init(const char* const (&streams)[Map::NSEG], char* smem, int wave, int lane) {
+        ring.init(streams, smem, wave, lane);
+        b16_lo = ring.lane_lo, b16_hi = ring.lane_hi;
+        b8_lo = opaque((lds_cptr)smem + lane * 8);
+        b8_hi = opaque((lds_cptr)smem + 65536 + lane * 8);
+    }
+    template <int OFF>
+    __device__ __forceinline__ half8 read16() const {
+        constexpr int o = OFF % C::RING_BYTES;
+        typedef __attribute__((address_space(3))) const half8* p_t;
+        if constexpr (o < 65536) return *(p_t)(b16_lo + o);
+        else return *(p_t)(b16_hi + (o - 65536));
+    }
+    template <int OFF>
+    __device__ __forceinline__ u2v read8() const {
+        constexpr int o = OFF % C::RING_BYTES;
+        typedef __attribute__((address_space(3))) const u2v* p_t;
+        if constexpr (o < 65536) return *(p_t)(b8_lo + o);
+        else return *(p_t)(b8_hi + (o - 65536));
+    }
+    static constexpr int chunk_hi(int qi) {
+        const int size = T.npe[qi] ? T.npe[qi] * 2048 : kMxKGroupBytes;
+        return (T.off[qi] + size - 1) / kChunkBytes;
+    }
+    template <int Q, int NQ>
+    __device__ __forceinline__ void fetch() {
+        if constexpr (Q < NQ) {
+            Slot& s = q[Q & 1];
+            constexpr int off = T.off[Q];
+            if constexpr (T.npe[Q] == 0) {
+                static_for<5>([&](auto i) { s.u[decltype(i)::value] = read16<off + 1024 * decltype(i)::value>(); });
+                s.up = read8<off + 5120>();
+            } else {
+                static_for<2 * T.npe[Q]>([&](auto i) { s.u[decltype(i)::value] = read16<off + 1024 * decltype(i)::value>(); });
+            }
+        }
+    }
+    // ring prologue was issued by the caller (ring.prologue()); wait for chunks 0,1 and read group Q0
+    template <int Q0, int NQ>
+    __device__ __forceinline__ void start() {
+        static_assert(chunk_hi(Q0) <= 1, "first group must lie in chunks 0..1");
+        ring.start_ring();
+        fetch<Q0, NQ>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // group Q is needed now: retire its reads, acquire the chunks group Q+1 touches, start reading group Q+1
+    template <int Q, int NQ>
+    __device__ __forceinline__ const Slot& use() {
+        Slot& s = q[Q & 1];
+        constexpr int nu = T.npe[Q] ? 2 * T.npe[Q] : 5;
+#pragma unroll
+        for (int j = 0; j < nu; ++j) asm volatile("" ::"v"(s.u[j]));  // the lgkmcnt(0) wait lands here
+        if constexpr (T.npe[Q] == 0) asm volatile("" ::"v"(s.up));
+        if constexpr (Q + 1 < NQ) {
+            constexpr int c0 = chunk_hi(Q) > 1 ? chunk_hi(Q) : 1, c1 = chunk_hi(Q + 1) - 1;
+            static_for<(c1 >= c0 ? c1 - c0 + 1 : 0)>([&](auto i) { ring.template boundary<c0 + decltype(i)::value>(); });
+            fetch<Q + 1, NQ>();
+        }
+        return s;
+    }
+};
+
+__device__ __forceinline__ i8v widen6(u6v r) {
+    return i8v{(int)r[0], (int)r[1], (int)r[2], (int)r[3], (int)r[4], (int)r[5], 0, 0};
+}
+// acc += (A6 * 2^(sa.byte[OPA]-127)) . (B6 * 2^(sb.byte[OPB]-127)),  16x16x128, both operands e2m3
+template <int OPA, int OPB>
+__device__ __forceinline__ float4v mfma_fp6(u6v a, u6v b, float4v c, int sa, int sb) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(widen6(a), widen6(b), c, 2, 2, OPA, sa, OPB, sb);
+}
+__device__ __forceinline__ u6v cvt_fp6(half8 a, half8 b, half8 c, half8 d, float scale) {
+    half32 v = __builtin_shufflevector(__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15),
+                                       __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15),
+                                       0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23,
+                                       24, 25, 26, 27, 28, 29, 30, 31);
+    return __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v, scale);
+}
+
+// Activations of one layer as the next layer's B operands: h[4*NKB] fp16 k-steps, h6 / l6 fp6 blocks,
+// sc = E8M0 bytes (byte 0: h6, byte 1: l6).  l16 is the staging area of the block being produced.
+template <int NKB>
+struct MxAct {
+    half8 h[4 * NKB];
+    u6v h6[NKB], l6[NKB];
+    int sc[NKB];
+};
+
+// ReLU + split of one HALF of row tile RT's accumulator; closes k block RT/8 when its last values arrive.
+// lo is kept scaled by 2^11 (so that fp16 holds it without going subnormal) until it becomes fp6.
+template <int RT, int HALF, int NKB>
+__device__ __forceinline__ void mx_store_act(const float4v& acc, MxAct<NKB>& y, half8 (&l16)[4]) {
+    constexpr int ks = RT / 2, e0 = (RT & 1) * 4 + 2 * HALF;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const float v = relu(acc[2 * HALF + r]);
+        const half_t h = (half_t)v;
+        y.h[ks][e0 + r] = h;
+        l16[ks & 3][e0 + r] = (half_t)((v - (float)h) * 2048.0f);
+    }
+    if constexpr ((RT & 7) == 7 && HALF == 1) {
+        constexpr int kb = RT / 8;
+        half8 m = __builtin_elementwise_max(__builtin_elementwise_max(y.h[4 * kb], y.h[4 * kb + 1]),
+                                            __builtin_elementwise_max(y.h[4 * kb + 2], y.h[4 * kb + 3]));
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+        half4 m4 = __builtin_elementwise_max(__builtin_shufflevector(m, m, 0, 1, 2, 3), __builtin_shufflevector(m, m, 4, 5, 6, 7));
+        half2v m2 = __builtin_elementwise_max(__builtin_shufflevector(m4, m4, 0, 1), __builtin_shufflevector(m4, m4, 2, 3));
+        const half_t mx = m2[0] > m2[1] ? m2[0] : m2[1];
+        // block max in [2^E, 2^(E+1)) -> scale 2^(E-1): codes in [2,4), no saturation.  fp16 exponent field e16 = E+15.
+        const int e16 = (__builtin_bit_cast(unsigned short, mx) >> 10) & 31;
+        const int byte_h = e16 + 111;  // E - 1 + 127
+        const float scale = __builtin_bit_cast(float, byte_h << 23);
+        y.h6[kb] = cvt_fp6(y.h[4 * kb], y.h[4 * kb + 1], y.h[4 * kb + 2], y.h[4 * kb + 3], scale);
+        y.l6[kb] = cvt_fp6(l16[0], l16[1], l16[2], l16[3], scale);
+        y.sc[kb] = byte_h | ((byte_h - 11) << 8);
+    }
+}
+
+// One dense layer.  Groups Q0 + rt*(NKB + (NPE>0)) + i.  X: activation operands (NKB blocks), Ph/Pl: the NPE
+// fp16 hi/lo k-steps (encodings).  epi(ic<rt>, ic<half>, acc) as in dense_layer, NCT = 1.
+// rs_lane: LDS address of the row-exponent table + 2*(lane&15) (u16: byte 0 = Wh6 exponent, byte 1 = Wl6's).
+template <class C, int Q0, int NQ, int RT, int NKB, int NPE, int BIAS0, class Reader, class Epi>
+__device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cptr rs_lane, const MxAct<(NKB ? NKB : 1)>& X,
+                                         const half8 (&Ph)[NPE ? NPE : 1], const half8 (&Pl)[NPE ? NPE : 1], Epi&& epi) {
+    constexpr int GPR = NKB + (NPE ? 1 : 0);
+    typedef __attribute__((address_space(3))) const float4v* lds_f4;
+    typedef __attribute__((address_space(3))) const unsigned short* lds_u16;
+    float4v acc[2];
+    float4v bias[2];
+    int rs[2] = {0, 0};
+    bias[0] = *(lds_f4)(bias_lane + BIAS0 * 4);
+    if constexpr (NKB > 0) rs[0] = *(lds_u16)(rs_lane + BIAS0 * 2);
+    static_for<RT>([&](auto rt_) {
+        constexpr int rt = decltype(rt_)::value;
+        constexpr int cur = rt & 1;
+        acc[cur] = bias[cur];
+        static_for<GPR>([&](auto gi_) {
+            constexpr int gi = decltype(gi_)::value;
+            const auto& s = rd.template use<Q0 + rt * GPR + gi, NQ>();
+            if constexpr (gi == 0 && rt + 1 < RT) {
+                bias[cur ^ 1] = *(lds_f4)(bias_lane + (BIAS0 + 16 * (rt + 1)) * 4);
+                if constexpr (NKB > 0) rs[cur ^ 1] = *(lds_u16)(rs_lane + (BIAS0 + 16 * (rt + 1)) * 2);
+            }
+            if constexpr (gi < NKB) {
+                constexpr int kb = gi;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[cur] = mfma16(s.u[k], X.h[4 * kb + k], acc[cur]);
+                const u6v wl6 = {__builtin_bit_cast(u4v, s.u[4])[0], __builtin_bit_cast(u4v, s.u[4])[1],
+                                 __builtin_bit_cast(u4v, s.u[4])[2], __builtin_bit_cast(u4v, s.u[4])[3], s.up[0], s.up[1]};
+                acc[cur] = mfma_fp6<1, 0>(wl6, X.h6[kb], acc[cur], rs[cur], X.sc[kb]);
+                const float wscale = __builtin_bit_cast(float, (rs[cur] & 0xff) << 23);
+                const u6v wh6 = cvt_fp6(s.u[0], s.u[1], s.u[2], s.u[3], wscale);
+                acc[cur] = mfma_fp6<0, 1>(wh6, X.l6[kb], acc[cur], rs[cur], X.sc[kb]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NPE; ++k) {
+                    acc[cur] = mfma16(s.u[2 * k], Ph[k], acc[cur]);
+                    acc[cur] = mfma16(s.u[2 * k + 1], Ph[k], acc[cur]);
+                    acc[cur] = mfma16(s.u[2 * k], Pl[k], acc[cur]);
+                }
+            }
+            if constexpr (rt > 0) {  // deferred epilogue of the previous row tile, spread over this one's groups
+                if constexpr (GPR == 1) {
+                    epi(ic<rt - 1>{}, ic<0>{}, acc[cur ^ 1]);
+                    epi(ic<rt - 1>{}, ic<1>{}, acc[cur ^ 1]);
+                } else if constexpr (gi < 2) {
+                    epi(ic<rt - 1>{}, ic<gi>{}, acc[cur ^ 1]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    });
+    // hipcc's hazard model gives VALU readers of a v_mfma_scale_f32_16x16x128_f8f6f4 result the wait states of a
+    // 4-pass MFMA; on gfx950 hardware that is not enough (stale accumulators were read right behind the last fp6
+    // MFMA of a layer).  The deferred epilogues are >= 6 MFMAs behind; only this final one needs the explicit drain.
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[(RT - 1) & 1]));
+    epi(ic<RT - 1>{}, ic<0>{}, acc[(RT - 1) & 1]);
+    epi(ic<RT - 1>{}, ic<1>{}, acc[(RT - 1) & 1]);
+}
+
+}  // namespace tgtc

@@ -4,34 +4,10 @@
 #include "mlp_core.h"
 #include "mlp_pack.h"
 #include "mlp_layouts.h"
+#include "mlp_nerf_front.h"
+#include "mlp_nerf_mx.h"
 
 namespace tgtc {
-
-enum InMode { IN_RAYS = 0, IN_PTS = 1, IN_ENC = 2 };
-
-struct NerfArgs {
-    const char* bias;    // device: padded bias table
-    const char* stream;  // device: weight fragment stream
-    long long M;         // samples
-    int N;               // samples per ray (IN_RAYS)
-    // inputs
-    const double* rays_o;
-    const double* rays_d;
-    const float* ts;
-    const double* pts;
-    const double* dirs;
-    const float* pts_enc;
-    const float* dirs_enc;
-    // outputs (any may be null)
-    float* rgb;
-    float* sigma;
-    float* remap;
-    float* out_pts_enc;
-    float* out_dirs_enc;
-    // diagnostics (null in production): s_memtime stamps of the first 64 workgroups' waves at phase boundaries,
-    // [block][wave][32] -- only this buffer ever receives them
-    unsigned long long* stamps;
-};
 
 template <class C, int IN_MODE, bool FULL>
 __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES * C::WG_PER_CU / 4) nerf_mlp_kernel(NerfArgs a) {
@@ -52,45 +28,21 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES * C::WG_PER_CU / 4) 
             a.stamps[((size_t)blockIdx.x * C::NWAVES + wave) * 32 + i] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
+#ifdef TGTC_STAGGER
+    // two co-resident workgroups per CU run the same program: delay the second dispatch round by ~half a pass once,
+    // so that one workgroup's prologue / head layers overlap the other's dense layers from then on
+    if (C::WG_PER_CU == 2 && blockIdx.x >= 256 && blockIdx.x < 512) {
+#pragma unroll 1
+        for (int i = 0; i < TGTC_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 
     // ---- 1. inputs (ordinary loads first: once LDS-DMA is in flight hipcc drains vmcnt(0) for them)
     double pos[NCT][3], dir[NCT][3];
     long long sidx[NCT];
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) {
-        long long s = s_wave + c * 16 + n;
-        sidx[c] = s;
-        if (s >= a.M) s = a.M - 1;  // tail: duplicate the last sample, stores are masked
-        if constexpr (IN_MODE == IN_RAYS) {
-            const long long r = (unsigned)s / (unsigned)a.N;  // M < 2^31 is checked at launch
-            const double t = (double)a.ts[s];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                dir[c][k] = a.rays_d[r * 3 + k];
-                pos[c][k] = a.rays_o[r * 3 + k] + t * dir[c][k];  // rendering.py:27 / utils.py:529
-            }
-        } else if constexpr (IN_MODE == IN_PTS) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) pos[c][k] = a.pts[s * 3 + k], dir[c][k] = a.dirs[s * 3 + k];
-        }
-        if constexpr (IN_MODE != IN_ENC) {
-            // retire the loads before any LDS-DMA is issued (otherwise their wait drains the whole prefetch)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(pos[c][k]), "+v"(dir[c][k]));
-        }
-    }
-
+    nerf_load_samples<NCT, IN_MODE>(a, s_wave, n, pos, dir, sidx);
     half8 pe_h[2][NCT], pe_l[2][NCT], de_h[1][NCT], de_l[1][NCT];
-    if constexpr (IN_MODE == IN_ENC) {
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-            const long long s = sidx[c] < a.M ? sidx[c] : a.M - 1;
-            half8 h2[2], l2[2];
-            load_encoded_point<SPLIT>(a.pts_enc + s * 63, g, h2, l2);
-            pe_h[0][c] = h2[0], pe_h[1][c] = h2[1], pe_l[0][c] = l2[0], pe_l[1][c] = l2[1];
-            if constexpr (FULL) load_encoded_dir<SPLIT>(a.dirs_enc + s * 27, g, de_h[0][c], de_l[0][c]);
-        }
-    }
+    if constexpr (IN_MODE == IN_ENC) nerf_load_encoded<NCT, SPLIT, FULL>(a, sidx, g, pe_h, pe_l, de_h, de_l);
 
     // ---- 2. start the weight stream: bias table, then the first 8 chunks
     WeightStream<C, SingleStreamMap<NFRAG>> ws;
@@ -104,19 +56,7 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES * C::WG_PER_CU / 4) 
     ws.prologue();
 
     // ---- 3. positional encoding into B fragments (overlaps the prefetch latency)
-    if constexpr (IN_MODE != IN_ENC) {
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-            const bool live = sidx[c] < a.M;
-            half8 h2[2], l2[2];
-            encode_point<SPLIT, SPLIT>(pos[c], g, h2, l2,
-                                       (a.out_pts_enc && live) ? a.out_pts_enc + sidx[c] * 63 : nullptr);
-            pe_h[0][c] = h2[0], pe_h[1][c] = h2[1], pe_l[0][c] = l2[0], pe_l[1][c] = l2[1];
-            if constexpr (FULL)
-                encode_dir<SPLIT, SPLIT>(dir[c], g, de_h[0][c], de_l[0][c],
-                                         (a.out_dirs_enc && live) ? a.out_dirs_enc + sidx[c] * 27 : nullptr);
-        }
-    }
+    if constexpr (IN_MODE != IN_ENC) nerf_encode<NCT, SPLIT, FULL>(a, pos, dir, sidx, g, pe_h, pe_l, de_h, de_l);
 
     const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * g);
     stamp(2);
@@ -205,7 +145,7 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES * C::WG_PER_CU / 4) 
 }
 
 // ------------------------------------------------------------------------------------------------ host
-static std::vector<LayerSpec> nerf_specs(const tgtc_linear* l) {
+std::vector<LayerSpec> nerf_specs(const tgtc_linear* l) {
     std::vector<LayerSpec> v;
     auto add = [&](int idx, std::vector<Seg> segs) {
         v.push_back(LayerSpec{l[idx].weight, l[idx].bias, l[idx].out_features, l[idx].in_features, std::move(segs)});
@@ -259,6 +199,15 @@ static int dispatch_nerf(const tgtc_net* net, NerfArgs& a, hipStream_t st) {
     }
     return fail(TGTC_ERR_UNSUPPORTED, "development build: kernel not compiled");
 #else
+    if (net->precision == TGTC_PREC_FP16_FP6) {
+        if (a.M >= 0x7fffffffLL) return fail(TGTC_ERR_UNSUPPORTED, "nerf: too many samples in one launch (%lld)", a.M);
+        hipEvent_t* ev = g_ev[FULL ? 1 : 0];
+        if (ev[0]) TGTC_HIP_CHECK(hipEventRecord(ev[0], st));
+        const int rc = nerf_mx_launch(IN_MODE, FULL, a, st);
+        if (rc == TGTC_OK && ev[1]) TGTC_HIP_CHECK(hipEventRecord(ev[1], st));
+        ev[0] = ev[1] = nullptr;
+        return rc;
+    }
     if (net->precision == TGTC_PREC_FP16) return launch_nerf<CfgFast, IN_MODE, FULL>(a, st);
     return launch_nerf<CfgExact, IN_MODE, FULL>(a, st);
 #endif
@@ -277,7 +226,8 @@ using namespace tgtc;
 
 extern "C" int tgtc_nerf_create(const tgtc_linear* layers, int n_layers, int precision, tgtc_net** out) {
     TGTC_REQUIRE(layers && out, "nerf_create: null argument");
-    TGTC_REQUIRE(precision == TGTC_PREC_FP16 || precision == TGTC_PREC_FP16X3, "nerf_create: unknown precision %d", precision);
+    TGTC_REQUIRE(precision == TGTC_PREC_FP16 || precision == TGTC_PREC_FP16X3 || precision == TGTC_PREC_FP16_FP6,
+                 "nerf_create: unknown precision %d", precision);
     static const int want[12][2] = {{256, 63},  {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 319},
                                     {256, 256}, {256, 256}, {1, 256},   {256, 256}, {128, 283}, {3, 128}};
     if (n_layers != 12) return fail(TGTC_ERR_UNSUPPORTED, "nerf_create: expected the 12 linears of MLP_style (D=8), got %d", n_layers);
@@ -287,18 +237,29 @@ extern "C" int tgtc_nerf_create(const tgtc_linear* layers, int n_layers, int pre
             return fail(TGTC_ERR_UNSUPPORTED, "nerf_create: layer %d is %dx%d, kernels are built for %dx%d (D=8, W=256, PE 10/4, viewdirs)",
                         i, layers[i].out_features, layers[i].in_features, want[i][0], want[i][1]);
     }
-    const bool split = precision == TGTC_PREC_FP16X3;
-    PackedNet p = pack_layers(nerf_specs(layers), split);
-    if (p.n_frags != NerfLayout::kFragsFull || (int)p.bias.size() != NerfLayout::kBiasFloats)
-        return fail(TGTC_ERR_UNSUPPORTED, "nerf_create: internal layout mismatch (%d frags, %zu bias)", p.n_frags, p.bias.size());
-    for (int i = 0; i < 12; ++i)
-        if (p.frag0[i] != NerfLayout::frag0(i) || p.bias0[i] != NerfLayout::bias0(i))
-            return fail(TGTC_ERR_UNSUPPORTED, "nerf_create: internal layout mismatch at layer %d", i);
+    std::vector<char> bias_region, stream;
+    int n_frags = 0;
+    if (precision == TGTC_PREC_FP16_FP6) {
+        const int rc = nerf_mx_pack(layers, bias_region, stream);
+        if (rc != TGTC_OK) return rc;
+    } else {
+        PackedNet p = pack_layers(nerf_specs(layers), precision == TGTC_PREC_FP16X3);
+        if (p.n_frags != NerfLayout::kFragsFull || (int)p.bias.size() != NerfLayout::kBiasFloats)
+            return fail(TGTC_ERR_UNSUPPORTED, "nerf_create: internal layout mismatch (%d frags, %zu bias)", p.n_frags, p.bias.size());
+        for (int i = 0; i < 12; ++i)
+            if (p.frag0[i] != NerfLayout::frag0(i) || p.bias0[i] != NerfLayout::bias0(i))
+                return fail(TGTC_ERR_UNSUPPORTED, "nerf_create: internal layout mismatch at layer %d", i);
+        bias_region.assign(kNerfBiasBytes, 0);
+        std::memcpy(bias_region.data(), p.bias.data(), p.bias.size() * sizeof(float));
+        stream.assign(reinterpret_cast<const char*>(p.stream.data()),
+                      reinterpret_cast<const char*>(p.stream.data()) + p.stream.size() * sizeof(half_t));
+        n_frags = p.n_frags;
+    }
     tgtc_net* net = new tgtc_net();
     net->kind = 0, net->precision = precision;
     net->bias_bytes = kNerfBiasBytes;
-    net->stream_bytes = p.stream.size() * sizeof(half_t);
-    net->n_frags = p.n_frags;
+    net->stream_bytes = stream.size();
+    net->n_frags = n_frags;
     // + one ring of slack so the last prefetches of a sigma-only pass never leave the allocation
     const size_t total = net->bias_bytes + net->stream_bytes + kChunkBytes;
     hipError_t e = hipMalloc((void**)&net->dev, total);
@@ -307,8 +268,8 @@ extern "C" int tgtc_nerf_create(const tgtc_linear* layers, int n_layers, int pre
         return fail(TGTC_ERR_HIP, "nerf_create: hipMalloc(%zu): %s", total, hipGetErrorString(e));
     }
     std::vector<char> host(total, 0);
-    memcpy(host.data(), p.bias.data(), p.bias.size() * sizeof(float));
-    memcpy(host.data() + net->bias_bytes, p.stream.data(), net->stream_bytes);
+    std::memcpy(host.data(), bias_region.data(), bias_region.size());
+    std::memcpy(host.data() + net->bias_bytes, stream.data(), net->stream_bytes);
     e = hipMemcpy(net->dev, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(net->dev);

@@ -1,0 +1,232 @@
+// Fused positional encoding + NeRF MLP in TGTC_PREC_FP16_FP6 (see mlp_mx.h for the arithmetic, mlp_nerf.hip for
+// the network: reference models.py:63-117 MLP_style inside :182-223 StyleNerf).
+#include "mlp_nerf_mx.h"
+
+#include "mlp_layouts.h"
+#include "mlp_mx.h"
+
+namespace tgtc {
+
+using CfgMx = MlpCfg<8, 1, false, 4>;
+
+constexpr int mx_bytes_upto(const MxTable& t, int nq) {
+    const int end = t.off[nq - 1] + (t.npe[nq - 1] ? t.npe[nq - 1] * 2048 : kMxKGroupBytes);
+    return (end + kChunkBytes - 1) / kChunkBytes * kChunkBytes;
+}
+
+template <int IN_MODE, bool FULL>
+__global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
+    using C = CfgMx;
+    using L = NerfLayout;
+    constexpr int NQ = FULL ? kNerfMxTable.first[12] : kNerfMxTable.first[9];
+    constexpr int NUNITS = mx_bytes_upto(kNerfMxTable, NQ) / 1024;
+
+    __shared__ __attribute__((aligned(16))) char smem[C::RING_BYTES + kNerfBiasBytes];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, n = lane & 15;
+    const long long s_wave = (long long)blockIdx.x * C::SAMPLES_PER_WG + wave * C::SAMPLES_PER_WAVE;
+    auto stamp = [&](int i) {
+        if (a.stamps && blockIdx.x < 64 && lane == 0)
+            a.stamps[((size_t)blockIdx.x * C::NWAVES + wave) * 32 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+
+    // ---- 1. inputs
+    double pos[1][3], dir[1][3];
+    long long sidx[1];
+    nerf_load_samples<1, IN_MODE>(a, s_wave, n, pos, dir, sidx);
+    half8 pe_h[2][1], pe_l[2][1], de_h[1][1], de_l[1][1];
+    if constexpr (IN_MODE == IN_ENC) nerf_load_encoded<1, true, FULL>(a, sidx, g, pe_h, pe_l, de_h, de_l);
+
+    // ---- 2. bias / row-exponent table, then the first 8 chunks of the weight stream
+    MxReader<C, SingleStreamMap<NUNITS>, kNerfMxTable> rd;
+    const char* const streams[1] = {a.stream};
+    rd.init(streams, smem, wave, lane);
+#pragma unroll
+    for (int j = 0; j < kNerfBiasBytes / (C::NWAVES * 1024); ++j)
+        __builtin_amdgcn_global_load_lds(TGTC_GPTR(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16),
+                                         TGTC_LPTR(smem + C::RING_BYTES + (j * C::NWAVES + wave) * 1024), 16, 0, 0);
+    stamp(1);
+    rd.ring.prologue();
+
+    // ---- 3. positional encoding (hi + lo fp16 B fragments)
+    if constexpr (IN_MODE != IN_ENC) nerf_encode<1, true, FULL>(a, pos, dir, sidx, g, pe_h, pe_l, de_h, de_l);
+    const half8 Ph[2] = {pe_h[0][0], pe_h[1][0]}, Pl[2] = {pe_l[0][0], pe_l[1][0]};
+
+    const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * g);
+    const lds_cptr rs_lane = opaque((lds_cptr)smem + C::RING_BYTES + kNerfMxScaleOff + 2 * n);
+    stamp(2);
+    rd.template start<0, NQ>();
+    stamp(3);
+
+    // ---- 4. trunk
+    MxAct<2> X, Y;
+    MxAct<1> none;  // layers without an activation input
+    half8 l16[4];
+    const half8 nop[1] = {};
+    auto to_Y = [&](auto rt_, auto h_, const float4v& acc) { mx_store_act<decltype(rt_)::value, decltype(h_)::value>(acc, Y, l16); };
+    auto to_X = [&](auto rt_, auto h_, const float4v& acc) { mx_store_act<decltype(rt_)::value, decltype(h_)::value>(acc, X, l16); };
+    constexpr const MxTable& T = kNerfMxTable;
+
+    dense_mx<C, T.first[0], NQ, 16, 0, 2, L::bias0(0)>(rd, bias_lane, rs_lane, none, Ph, Pl, to_Y);
+    stamp(4);
+    dense_mx<C, T.first[1], NQ, 16, 2, 0, L::bias0(1)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
+    stamp(5);
+    dense_mx<C, T.first[2], NQ, 16, 2, 0, L::bias0(2)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
+    stamp(6);
+    dense_mx<C, T.first[3], NQ, 16, 2, 0, L::bias0(3)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
+    stamp(7);
+    dense_mx<C, T.first[4], NQ, 16, 2, 0, L::bias0(4)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
+    stamp(8);
+    // skip layer: reference input is cat(pe, h) (models.py:98-99); k order here is [h | pe]
+    dense_mx<C, T.first[5], NQ, 16, 2, 2, L::bias0(5)>(rd, bias_lane, rs_lane, Y, Ph, Pl, to_X);
+    stamp(9);
+    dense_mx<C, T.first[6], NQ, 16, 2, 0, L::bias0(6)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
+    stamp(10);
+    dense_mx<C, T.first[7], NQ, 16, 2, 0, L::bias0(7)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
+    stamp(11);
+
+    // ---- 5. sigma head (models.py:103): row 0 of a 16-row tile -> lanes 0..15, register 0
+    dense_mx<C, T.first[8], NQ, 1, 2, 0, L::bias0(8)>(rd, bias_lane, rs_lane, X, nop, nop, [&](auto, auto h_, const float4v& acc) {
+        if constexpr (decltype(h_)::value == 0)
+            if (g == 0 && a.sigma && sidx[0] < a.M) a.sigma[sidx[0]] = acc[0];
+    });
+    stamp(12);
+
+    if constexpr (FULL) {
+        // ---- 6. base_remap (models.py:106) and the colour head (models.py:107-111)
+        dense_mx<C, T.first[9], NQ, 16, 2, 0, L::bias0(9)>(rd, bias_lane, rs_lane, X, nop, nop, [&](auto rt_, auto h_, const float4v& acc) {
+            constexpr int rt = decltype(rt_)::value, hf = decltype(h_)::value;
+            mx_store_act<rt, hf>(acc, Y, l16);
+            if (a.remap && sidx[0] < a.M) {
+                float* o = a.remap + sidx[0] * 256 + 16 * rt + 4 * g + 2 * hf;
+                o[0] = relu(acc[2 * hf]), o[1] = relu(acc[2 * hf + 1]);
+            }
+        });
+        MxAct<1> Z;
+        const half8 Dh[1] = {de_h[0][0]}, Dl[1] = {de_l[0][0]};
+        dense_mx<C, T.first[10], NQ, 8, 2, 1, L::bias0(10)>(rd, bias_lane, rs_lane, Y, Dh, Dl, [&](auto rt_, auto h_, const float4v& acc) {
+            mx_store_act<decltype(rt_)::value, decltype(h_)::value>(acc, Z, l16);
+        });
+        dense_mx<C, T.first[11], NQ, 1, 1, 0, L::bias0(11)>(rd, bias_lane, rs_lane, Z, nop, nop, [&](auto, auto h_, const float4v& acc) {
+            constexpr int hf = decltype(h_)::value;
+            if (g == 0 && a.rgb && sidx[0] < a.M) {
+#pragma unroll
+                for (int r = 2 * hf; r < (hf ? 3 : 2); ++r) a.rgb[sidx[0] * 3 + r] = 1.0f / (1.0f + expf(-acc[r]));
+            }
+        });
+        stamp(13);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+static int e2m3_encode(float x) {
+    float a = std::fabs(x);
+    if (!(a < 7.5f)) a = 7.5f;
+    // position on the (piecewise linear) code axis, then round to nearest, ties to even code
+    const float q = a < 1.0f ? a * 8.0f : (a < 2.0f ? 8.0f + (a - 1.0f) * 8.0f : (a < 4.0f ? 16.0f + (a - 2.0f) * 4.0f : 24.0f + (a - 4.0f) * 2.0f));
+    int c = (int)std::nearbyint(q);  // default rounding mode: ties to even
+    if (c > 31) c = 31;
+    return c | (std::signbit(x) ? 32 : 0);
+}
+
+int nerf_mx_pack(const tgtc_linear* layers, std::vector<char>& bias_region, std::vector<char>& stream) {
+    const std::vector<LayerSpec> specs = nerf_specs(layers);
+    const MxTable& T = kNerfMxTable;
+    bias_region.assign(kNerfBiasBytes, 0);
+    stream.assign((size_t)T.bytes, 0);
+    float* bias = reinterpret_cast<float*>(bias_region.data());
+    unsigned short* rowexp = reinterpret_cast<unsigned short*>(bias_region.data() + kNerfMxScaleOff);
+    static_assert(kNerfMxScaleOff >= NerfLayout::kBiasFloats * 4 && kNerfMxScaleOff + NerfLayout::kBiasFloats * 2 <= kNerfBiasBytes,
+                  "row exponent table must fit behind the biases");
+    int qi = 0, b0 = 0;
+    for (size_t l = 0; l < specs.size(); ++l) {
+        const LayerSpec& Ls = specs[l];
+        const MxShape sh = kNerfMxShape[l];
+        if (Ls.row_tiles() != sh.rt || qi != T.first[l] || b0 != NerfLayout::bias0((int)l))
+            return fail(TGTC_ERR_UNSUPPORTED, "nerf_create: internal fp16+fp6 layout mismatch at layer %zu", l);
+        const Seg* act = nullptr;
+        const Seg* pe = nullptr;
+        for (const Seg& s : Ls.segs) (s.kind == SEG_ACT ? act : pe) = &s;
+        if ((act ? act->ksteps : 0) != 4 * sh.nkb || (pe ? pe->ksteps : 0) != sh.npe)
+            return fail(TGTC_ERR_UNSUPPORTED, "nerf_create: internal fp16+fp6 segment mismatch at layer %zu", l);
+        auto weight = [&](int row, int col) -> float {
+            return (row < Ls.out && col >= 0 && col < Ls.in) ? Ls.W[(size_t)row * Ls.in + col] : 0.0f;
+        };
+        for (int rt = 0; rt < sh.rt; ++rt) {
+            int E[16];  // exponent of the largest |fp16(w)| of each row over the activation columns
+            for (int r = 0; r < 16; ++r) {
+                const int row = 16 * rt + r;
+                bias[b0 + 16 * rt + r] = row < Ls.out ? Ls.b[row] : 0.0f;
+                float mx = 0.0f;
+                if (act)
+                    for (int c = 0; c < 128 * sh.nkb; ++c) mx = std::fmax(mx, std::fabs((float)(half_t)weight(row, act->col0 + c)));
+                int e = -14;
+                if (mx > 0.0f) {
+                    (void)std::frexp(mx, &e);  // mx = f * 2^e, f in [0.5, 1)
+                    e -= 1;
+                    if (e < -14) e = -14;
+                }
+                E[r] = e;
+                const int byte_h = e - 1 + 127;
+                rowexp[b0 + 16 * rt + r] = (unsigned short)(byte_h | ((byte_h - 11) << 8));
+            }
+            for (int kb = 0; kb < sh.nkb; ++kb, ++qi) {
+                char* base = stream.data() + T.off[qi];
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int m = lane & 15, g = lane >> 4, row = 16 * rt + m;
+                    unsigned long long bits[3] = {0, 0, 0};
+                    const float inv = std::ldexp(1.0f, -(E[m] - 12));  // Wl6 scale 2^(E-1-11)
+                    for (int s = 0; s < 4; ++s)
+                        for (int j = 0; j < 8; ++j) {
+                            const float w = weight(row, seg_col(*act, 4 * kb + s, g, j));
+                            const half_t hi = (half_t)w;
+                            std::memcpy(base + s * 1024 + lane * 16 + j * 2, &hi, 2);
+                            const unsigned long long code = (unsigned long long)e2m3_encode((w - (float)hi) * inv);
+                            const int bit = 6 * (8 * s + j);
+                            bits[bit / 64] |= code << (bit % 64);
+                            if (bit % 64 > 58) bits[bit / 64 + 1] |= code >> (64 - bit % 64);
+                        }
+                    std::memcpy(base + 4096 + lane * 16, &bits[0], 16);
+                    std::memcpy(base + 5120 + lane * 8, &bits[2], 8);
+                }
+            }
+            if (sh.npe) {
+                char* base = stream.data() + T.off[qi];
+                for (int k = 0; k < sh.npe; ++k)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int m = lane & 15, g = lane >> 4, row = 16 * rt + m;
+                        for (int j = 0; j < 8; ++j) {
+                            const float w = weight(row, seg_col(*pe, k, g, j));
+                            const half_t hi = (half_t)w, lo = (half_t)(w - (float)hi);
+                            std::memcpy(base + (2 * k) * 1024 + lane * 16 + j * 2, &hi, 2);
+                            std::memcpy(base + (2 * k + 1) * 1024 + lane * 16 + j * 2, &lo, 2);
+                        }
+                    }
+                ++qi;
+            }
+        }
+        b0 += 16 * sh.rt;
+    }
+    if (qi != T.n) return fail(TGTC_ERR_UNSUPPORTED, "nerf_create: internal fp16+fp6 group count mismatch");
+    return TGTC_OK;
+}
+
+int nerf_mx_launch(int in_mode, bool full, const NerfArgs& a, hipStream_t st) {
+    using C = CfgMx;
+    const unsigned nwg = (unsigned)((a.M + C::SAMPLES_PER_WG - 1) / C::SAMPLES_PER_WG);
+    const dim3 block(C::NWAVES * 64);
+    switch (in_mode * 2 + (full ? 1 : 0)) {
+        case IN_RAYS * 2 + 0: nerf_mx_kernel<IN_RAYS, false><<<nwg, block, 0, st>>>(a); break;
+        case IN_RAYS * 2 + 1: nerf_mx_kernel<IN_RAYS, true><<<nwg, block, 0, st>>>(a); break;
+        case IN_PTS * 2 + 1: nerf_mx_kernel<IN_PTS, true><<<nwg, block, 0, st>>>(a); break;
+        case IN_ENC * 2 + 1: nerf_mx_kernel<IN_ENC, true><<<nwg, block, 0, st>>>(a); break;
+        default: return fail(TGTC_ERR_UNSUPPORTED, "nerf (fp16+fp6): no kernel for input mode %d, full %d", in_mode, (int)full);
+    }
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
+}
+
+}  // namespace tgtc

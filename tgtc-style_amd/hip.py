@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("TGTC_LIB") or os.path.join(_HERE, "csrc", "libtgtc_hi
 
 PREC_FP16X3 = 0   # split-fp16, fp32-equivalent (parity mode)
 PREC_FP16 = 1     # single fp16 MFMA product (fast mode)
-PRECISIONS = {"fp16x3": PREC_FP16X3, "fp16": PREC_FP16}
+PREC_FP16_FP6 = 2  # fp16 product + two block-scaled fp6 correction products (NeRF nets only)
+PRECISIONS = {"fp16x3": PREC_FP16X3, "fp16": PREC_FP16, "fp16mx": PREC_FP16_FP6}
 
 _lib = None
 
