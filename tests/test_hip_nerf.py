@@ -5,7 +5,8 @@ Tolerance (BASELINE.json north_star): RGB / sigma within 1e-3 relative of the fp
     err(a, ref) = max|a - ref| / max|ref|
 which is the meaningful reading for sigma (pre-activation values cross zero, where a pointwise
 ratio is unbounded).  Mode fp16x3 (the default, parity mode) must meet 1e-3 everywhere and in fact
-sits near 1e-5; mode fp16 (single fp16 MFMA product) is the documented fast mode and is held to 1e-2.
+sits near 1e-5; mode fp16mx (fp16 product + two block-scaled fp6 correction products) must meet 1e-3 as
+well and sits near 1e-4; mode fp16 (single fp16 MFMA product) is the documented fast mode and is held to 1e-2.
 """
 import numpy as np
 import pytest
@@ -16,9 +17,9 @@ from tgtc_style_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp16x3": 1e-3, "fp16": 1e-2}
-# what the split-fp16 path actually achieves; guards against silent precision regressions
-TIGHT = {"fp16x3": 5e-5, "fp16": 1e-2}
+TOL = {"fp16x3": 1e-3, "fp16mx": 1e-3, "fp16": 1e-2}
+# what each path actually achieves; guards against silent precision regressions
+TIGHT = {"fp16x3": 5e-5, "fp16mx": 5e-4, "fp16": 1e-2}
 
 
 def T(sd, cuda=False):
@@ -49,7 +50,7 @@ def make_nerf(seed, mode, precision):
     return m.cuda()
 
 
-@pytest.mark.parametrize("precision", ["fp16x3", "fp16"])
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16mx", "fp16"])
 def test_stylenerf_forward_golden(golden, precision):
     """StyleNerf.forward (models.py:216-223) on the reference's own outputs (g4)."""
     g = golden("g4_nerf")
@@ -72,7 +73,7 @@ def test_stylenerf_forward_golden(golden, precision):
         assert rel(out["dirs"][:, :8], g[name + "_dirs_enc_first8"]) <= 2e-7
 
 
-@pytest.mark.parametrize("precision", ["fp16x3", "fp16"])
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16mx", "fp16"])
 def test_mlp_style_forward_encoded_inputs(golden, precision):
     """MLP_style.forward (models.py:95-117) on already-encoded float32 inputs."""
     g = golden("g4_nerf")
@@ -97,7 +98,7 @@ def test_nerf_ragged_sizes(M):
     pts = torch.from_numpy(rng.uniform(-1.2, 1.2, (M, 3)))
     dirs = torch.from_numpy(rng.uniform(-1, 1, (M, 3)))
     ref = fields.style_nerf(T(synth.nerf_state(1)), pts, dirs)
-    for precision in ("fp16x3", "fp16"):
+    for precision in ("fp16x3", "fp16mx", "fp16"):
         out = make_nerf(1, "fine", precision)(pts=pts.cuda(), dirs=dirs.cuda())
         assert out["sigma"].shape == (M,)
         assert rel(out["sigma"], ref["sigma"]) <= TIGHT[precision] * 2
@@ -116,6 +117,36 @@ def test_nerf_empty_and_errors():
         hip.nerf_create({k: torch.from_numpy(v) for k, v in sd.items()}, "fp16x3")
     with pytest.raises(RuntimeError):
         m(pts=torch.zeros(4, 3, dtype=torch.float64), dirs=torch.zeros(4, 3, dtype=torch.float64))   # CPU tensors
+    # the fp16+fp6 mode exists for the NeRF nets only; the style nets refuse it instead of falling back
+    with pytest.raises(RuntimeError, match="NeRF nets only"):
+        hip.style_create({k: torch.from_numpy(v) for k, v in synth.concat_state(0).items()},
+                         {k: torch.from_numpy(v) for k, v in synth.style_state(0).items()}, "fp16mx")
+
+
+@pytest.mark.parametrize("log2_range,bound", [(0, 5e-4), (3, 1e-3)])
+def test_fp16mx_dynamic_range(log2_range, bound):
+    """fp16mx corrections are block scaled (one exponent per weight row, one per 32 activations of a lane), so
+    their benefit shrinks as the dynamic range inside a block grows; in the limit the mode degrades to plain
+    fp16, never below it.  Rows of layers 1-3 are scaled by 2^U(-r, r) and the next layer's columns by the
+    inverse (the function is unchanged, ReLU being positively homogeneous): at r = 3 (a 64 x spread between
+    neighbouring features) the 1e-3 bar still holds on every output of the network."""
+    sd = {k: v.copy() for k, v in synth.nerf_state(1).items()}
+    rng = np.random.default_rng(5)
+    for i in (1, 2, 3):
+        s = (2.0 ** rng.integers(-log2_range, log2_range + 1, 256)).astype(np.float32)
+        sd["net.base_layers.%d.weight" % i] *= s[:, None]
+        sd["net.base_layers.%d.bias" % i] *= s
+        sd["net.base_layers.%d.weight" % (i + 1)][:, -256:] /= s[None, :]
+    pts = torch.from_numpy(rng.uniform(-1, 1, (512, 3)))
+    dirs = torch.from_numpy(rng.uniform(-1, 1, (512, 3)))
+    ref = fields.style_nerf(T(sd), pts, dirs)
+    from tgtc_style_amd import models
+    m = models.StyleNerf(type("A", (Args,), {"precision": "fp16mx"}), mode="fine")
+    m.load_state_dict(T(sd))
+    out = m.cuda()(pts=pts.cuda(), dirs=dirs.cuda())
+    errs = {k: rel(out[k], ref[k]) for k in ("sigma", "rgb", "base_remap")}
+    print("fp16mx, spread 2^+-%d:" % log2_range, errs)
+    assert max(errs.values()) <= bound, errs
 
 
 def test_repack_on_weight_change():
@@ -128,7 +159,7 @@ def test_repack_on_weight_change():
     assert not torch.allclose(a, b) and rel(b, ref) <= 5e-5
 
 
-@pytest.mark.parametrize("precision", ["fp16x3", "fp16"])
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16mx", "fp16"])
 @pytest.mark.parametrize("nc,nf", [(128, 64), (64, 64)])
 def test_render_rays_plain_golden(golden, precision, nc, nf):
     """The fused cal_geometry chain (rendering.py:27-51) against the reference's own render of 64 rays."""
@@ -142,8 +173,11 @@ def test_render_rays_plain_golden(golden, precision, nc, nf):
     e_rgb = float((out["rgb"].cpu() - torch.from_numpy(g["plain_rgb" + tag])).abs().max())
     e_t = float((out["t"].cpu() - torch.from_numpy(g["plain_t" + tag])).abs().max())
     print(precision, tag, "rgb", e_rgb, "t", e_t)
-    lim = {"fp16x3": 1e-3, "fp16": 2e-2}[precision]
-    assert e_rgb <= lim and e_t <= lim
+    lim = {"fp16x3": 1e-3, "fp16mx": 1e-3, "fp16": 2e-2}[precision]
+    # the composited depth rides on the inverse-CDF positions, which amplify sigma errors: fp16mx (sigma 1.5e-4) holds the
+    # 1e-3 bar on colour but only 5e-3 on depth -- one reason fp16x3 stays the default parity mode
+    lim_t = 5e-3 if precision == "fp16mx" else lim
+    assert e_rgb <= lim and e_t <= lim_t
     # same chain assembled from the granular operators (what rendering.cal_geometry does) agrees with the fused call
     ref = fields.render_plain(T(synth.nerf_state(0)), T(synth.nerf_state(1)), ro.cpu(), rd.cpu(), nc, nf)
     assert float((out["rgb_coarse"].cpu() - ref["rgb_coarse"]).abs().max()) <= lim

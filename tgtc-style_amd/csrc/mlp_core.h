@@ -39,6 +39,21 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
+// LDS-DMA: 16 bytes per lane from global memory to  lds_dst (wave-uniform) + lane*16.
+// With TGTC_ASM_DMA the instruction is emitted through inline asm: hipcc's waitcnt insertion treats a
+// global_load_lds it can see as an LDS event of a second kind, and from then on every wait for a ds_read is
+// `lgkmcnt(0)` instead of a counted wait (each LDS read then waits for ALL outstanding reads).  Hidden in asm, the
+// ds_reads get exact counted waits; the DMA's own completion is tracked by hand anyway (wait_vmcnt + s_barrier).
+// M0 carries the LDS destination; nothing else in these kernels uses M0.
+__device__ __forceinline__ void lds_dma16(const char* gsrc, char* lds_dst) {
+#ifdef TGTC_ASM_DMA
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)TGTC_LPTR(lds_dst));
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "memory");
+#else
+    __builtin_amdgcn_global_load_lds(TGTC_GPTR(gsrc), TGTC_LPTR(lds_dst), 16, 0, 0);
+#endif
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
@@ -48,8 +63,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 // ------------------------------------------------------------------------------------------------
 // Geometry shared by the packer (host) and the kernels (device).
 constexpr int kFragHalves = 64 * 8;       // one MFMA A fragment: 64 lanes x 8 halves = 1 KiB
-constexpr int kChunkBytes = 16384;        // ring granule
-constexpr int kRingSlots = 8;             // 128 KiB ring
+#ifndef TGTC_CHUNK_BYTES
+#define TGTC_CHUNK_BYTES 16384
+#endif
+constexpr int kChunkBytes = TGTC_CHUNK_BYTES;           // ring granule
+constexpr int kRingSlots = 131072 / kChunkBytes;         // 128 KiB ring
 constexpr int kRingBytes = kChunkBytes * kRingSlots;
 constexpr int kPrefetchDepth = kRingSlots - 1;
 
@@ -144,9 +162,7 @@ struct WeightStream {
             asm volatile("" : "+v"(base));
 #pragma unroll
             for (int j = 0; j < C::GPC; ++j)
-                __builtin_amdgcn_global_load_lds(TGTC_GPTR(base + off + j * 1024),
-                                                 TGTC_LPTR(lds_wave + (CH % C::SLOTS) * kChunkBytes + j * 1024),
-                                                 16, 0, 0);
+                lds_dma16(base + off + j * 1024, lds_wave + (CH % C::SLOTS) * kChunkBytes + j * 1024);
         }
     }
     __device__ __forceinline__ void prologue() const {

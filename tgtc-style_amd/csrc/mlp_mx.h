@@ -3,7 +3,7 @@
 //   W = Wh + Wl (Wh = fp16(W)),  a = Ah + Al (Ah = fp16(a));   W.a ~= Wh.Ah + Wl.Ah + Wh.Al
 //   main   Wh.Ah  on v_mfma_f32_16x16x32_f16                     (4 instructions per 128-deep k block)
 //   corr1  Wl.Ah  on v_mfma_scale_f32_16x16x128_f8f6f4 (e2m3)    (1 instruction: Wl6 from the stream, Ah6 from registers)
-//   corr2  Wh.Al  on the same instruction                        (1 instruction: Wh6 converted from Wh in registers, Al6)
+//   corr2  Wh.Al  on the same instruction                        (1 instruction: Wh6 from the stream, Al6 from registers)
 // Both correction terms are ~2^-11 of the main term, so their 4-bit (e2m3) operands leave a relative error of
 // ~2^-16 per product -- 30 x better than the single fp16 product -- at 6.15 MFMA issue slots per block instead
 // of the 12 of TGTC_PREC_FP16X3 (an fp6 16x16x128 costs about what an f16 16x16x32 costs, tools/microbench/mfma_fp6).
@@ -12,7 +12,9 @@
 // lane holds.  Lane maps (probed in tools/microbench/mfma_fp6_check.py): lane l holds row/column l&15 and the 32
 // consecutive k = 32(l>>4)+i, six bits each, little endian; code = e2m3(value / scale), RNE, saturating.
 // The 32 values a lane holds for four consecutive fp16 k-steps s (element j) are the SAME logical k values
-// (i = 8s+j), so Ah6 / Wh6 are one v_cvt_scalef32_pk32_fp6_f16 of registers that already exist.
+// (i = 8s+j), so Ah6 is one v_cvt_scalef32_pk32_fp6_f16 of registers that already exist.  That instruction
+// costs ~100 cycles (tools/microbench/mx_parts), fine once per 128 outputs of an activation block, far too
+// slow once per weight group -- so Wh6 is packed on the host and streamed like Wl6.
 //
 // Positional-encoding / direction k-steps keep the three-product fp16 scheme (their B fragments do not come
 // out of an accumulator); NCT = 1 column tile per wave.
@@ -29,14 +31,16 @@ typedef _Float16 half32 __attribute__((ext_vector_type(32)));
 
 // ------------------------------------------------------------------------------------------------ stream layout
 // The stream is a sequence of GROUPS, one LDS->register burst each:
-//   K group (one 128-deep block of one row tile), 5632 B: [Wh k-step 0..3: 4 x 1 KiB, lane*16]
-//                                                         [Wl6 dwords 0-3: 1 KiB, lane*16][Wl6 dwords 4-5: 512 B, lane*8]
+//   K group (one 128-deep block of one row tile), 7 KiB:  [Wh k-step 0..3: 4 x 1 KiB][Wl6 dwords 0-3: 1 KiB]
+//                                                         [Wh6 dwords 0-3: 1 KiB], lane*16; [Wl6 dwords 4-5: 512 B]
+//                                                         [Wh6 dwords 4-5: 512 B], lane*8 -- so that each fp6 operand
+//                                                         lands in six consecutive registers without copies
 //   P group (the PE / direction k-steps of one row tile), npe x 2 KiB: [hi, lo] per k-step, lane*16
 // Groups never straddle the end of the 128 KiB ring (padding inserted), they may straddle 16 KiB chunks.
 struct MxShape {
     int rt, nkb, npe;
 };
-constexpr int kMxKGroupBytes = 5632;
+constexpr int kMxKGroupBytes = 7168;
 constexpr int kMxMaxGroups = 512;
 
 struct MxTable {
@@ -83,29 +87,29 @@ __host__ __device__ inline float e2m3_value(int code) {
 }
 
 // ------------------------------------------------------------------------------------------------ device side
+// LDS -> register staging of one group at a time.  The register budget (8 waves x 256 VGPRs, two layers of
+// activations resident) has no room for a second group buffer, so the NEXT group's units are read into the
+// registers of the current group as soon as the MFMA that consumed each of them has issued (refill<>), and the
+// single lgkmcnt(0) the compiler emits lands at the start of the next group (acquire<>).
 template <class C, class Map, const MxTable& T>
 struct MxReader {
     using Ring = WeightStream<C, Map>;
-    struct Slot {
-        half8 u[5];
-        u2v up;
-    };
     Ring ring;
-    lds_cptr b16_lo, b16_hi, b8_lo, b8_hi;  // ring + lane*16 / lane*8, lower / upper 64 KiB
-    Slot q[2];
+    lds_cptr b8_lo, b8_hi;  // ring + lane*8, lower / upper 64 KiB
+    half8 u[4];             // units 0..3: fp16 fragments (K group: Wh k-steps; P group: hi/lo pairs)
+    u6v w6[2];              // K group: Wl6 (units 4 = dwords 0-3, 6 = dwords 4-5), Wh6 (units 5, 7)
 
     __device__ __forceinline__ void init(const char* const (&streams)[Map::NSEG], char* smem, int wave, int lane) {
         ring.init(streams, smem, wave, lane);
-        b16_lo = ring.lane_lo, b16_hi = ring.lane_hi;
         b8_lo = opaque((lds_cptr)smem + lane * 8);
-        b8_hi = opaque((lds_cptr)smem + 65536 + lane * 8);
+        b8_hi = opaque((lds_cptr)smem + (C::RING_BYTES > 65536 ? 65536 : 0) + lane * 8);
     }
     template <int OFF>
     __device__ __forceinline__ half8 read16() const {
         constexpr int o = OFF % C::RING_BYTES;
         typedef __attribute__((address_space(3))) const half8* p_t;
-        if constexpr (o < 65536) return *(p_t)(b16_lo + o);
-        else return *(p_t)(b16_hi + (o - 65536));
+        if constexpr (o < 65536) return *(p_t)(ring.lane_lo + o);
+        else return *(p_t)(ring.lane_hi + (o - 65536));
     }
     template <int OFF>
     __device__ __forceinline__ u2v read8() const {
@@ -114,45 +118,49 @@ struct MxReader {
         if constexpr (o < 65536) return *(p_t)(b8_lo + o);
         else return *(p_t)(b8_hi + (o - 65536));
     }
-    static constexpr int chunk_hi(int qi) {
-        const int size = T.npe[qi] ? T.npe[qi] * 2048 : kMxKGroupBytes;
-        return (T.off[qi] + size - 1) / kChunkBytes;
-    }
-    template <int Q, int NQ>
-    __device__ __forceinline__ void fetch() {
+    static constexpr int units(int qi) { return T.npe[qi] ? 2 * T.npe[qi] : 8; }
+    static constexpr int bytes(int qi) { return T.npe[qi] ? 2048 * T.npe[qi] : kMxKGroupBytes; }
+    static constexpr int chunk_hi(int qi) { return (T.off[qi] + bytes(qi) - 1) / kChunkBytes; }
+    // read unit J of group Q (no-op past the end of the stream / of the group)
+    template <int Q, int NQ, int J>
+    __device__ __forceinline__ void refill() {
         if constexpr (Q < NQ) {
-            Slot& s = q[Q & 1];
-            constexpr int off = T.off[Q];
-            if constexpr (T.npe[Q] == 0) {
-                static_for<5>([&](auto i) { s.u[decltype(i)::value] = read16<off + 1024 * decltype(i)::value>(); });
-                s.up = read8<off + 5120>();
-            } else {
-                static_for<2 * T.npe[Q]>([&](auto i) { s.u[decltype(i)::value] = read16<off + 1024 * decltype(i)::value>(); });
+#ifdef TGTC_MX_X_NOLDS   // timing experiment: only the first groups are really read
+            if constexpr (Q > 4) return;
+#endif
+            if constexpr (J < units(Q)) {
+                if constexpr (J < 4) {
+                    u[J] = read16<T.off[Q] + 1024 * J>();
+                } else if constexpr (J < 6) {
+                    const u4v t = __builtin_bit_cast(u4v, read16<T.off[Q] + 1024 * J>());
+                    w6[J - 4][0] = t[0], w6[J - 4][1] = t[1], w6[J - 4][2] = t[2], w6[J - 4][3] = t[3];
+                } else {
+                    const u2v t = read8<T.off[Q] + 6144 + 512 * (J - 6)>();
+                    w6[J - 6][4] = t[0], w6[J - 6][5] = t[1];
+                }
             }
         }
+    }
+    // units [J0, 8) of group Q
+    template <int Q, int NQ, int J0>
+    __device__ __forceinline__ void refill_from() {
+        static_for<8 - J0>([&](auto j) { refill<Q, NQ, J0 + decltype(j)::value>(); });
     }
     // ring prologue was issued by the caller (ring.prologue()); wait for chunks 0,1 and read group Q0
     template <int Q0, int NQ>
     __device__ __forceinline__ void start() {
         static_assert(chunk_hi(Q0) <= 1, "first group must lie in chunks 0..1");
         ring.start_ring();
-        fetch<Q0, NQ>();
+        refill_from<Q0, NQ, 0>();
         __builtin_amdgcn_sched_barrier(0);
     }
-    // group Q is needed now: retire its reads, acquire the chunks group Q+1 touches, start reading group Q+1
+    // entering group Q: acquire the chunks group Q+1 touches
     template <int Q, int NQ>
-    __device__ __forceinline__ const Slot& use() {
-        Slot& s = q[Q & 1];
-        constexpr int nu = T.npe[Q] ? 2 * T.npe[Q] : 5;
-#pragma unroll
-        for (int j = 0; j < nu; ++j) asm volatile("" ::"v"(s.u[j]));  // the lgkmcnt(0) wait lands here
-        if constexpr (T.npe[Q] == 0) asm volatile("" ::"v"(s.up));
+    __device__ __forceinline__ void acquire() {
         if constexpr (Q + 1 < NQ) {
             constexpr int c0 = chunk_hi(Q) > 1 ? chunk_hi(Q) : 1, c1 = chunk_hi(Q + 1) - 1;
             static_for<(c1 >= c0 ? c1 - c0 + 1 : 0)>([&](auto i) { ring.template boundary<c0 + decltype(i)::value>(); });
-            fetch<Q + 1, NQ>();
         }
-        return s;
     }
 };
 
@@ -193,7 +201,11 @@ __device__ __forceinline__ void mx_store_act(const float4v& acc, MxAct<NKB>& y, 
         y.h[ks][e0 + r] = h;
         l16[ks & 3][e0 + r] = (half_t)((v - (float)h) * 2048.0f);
     }
+#ifdef TGTC_MX_X_NOCVT  // timing experiment: no block conversion
+    if constexpr (false) {
+#else
     if constexpr ((RT & 7) == 7 && HALF == 1) {
+#endif
         constexpr int kb = RT / 8;
         half8 m = __builtin_elementwise_max(__builtin_elementwise_max(y.h[4 * kb], y.h[4 * kb + 1]),
                                             __builtin_elementwise_max(y.h[4 * kb + 2], y.h[4 * kb + 3]));
@@ -215,63 +227,114 @@ __device__ __forceinline__ void mx_store_act(const float4v& acc, MxAct<NKB>& y, 
 // One dense layer.  Groups Q0 + rt*(NKB + (NPE>0)) + i.  X: activation operands (NKB blocks), Ph/Pl: the NPE
 // fp16 hi/lo k-steps (encodings).  epi(ic<rt>, ic<half>, acc) as in dense_layer, NCT = 1.
 // rs_lane: LDS address of the row-exponent table + 2*(lane&15) (u16: byte 0 = Wh6 exponent, byte 1 = Wl6's).
-template <class C, int Q0, int NQ, int RT, int NKB, int NPE, int BIAS0, class Reader, class Epi>
+// Two accumulator chains per row tile -- main (bias + fp16 products) and corr (fp6 products), summed in the
+// epilogue -- so that consecutive MFMAs are not all dependent on each other.  The instruction order is pinned
+// step by step (sched_barrier): one MFMA, the refill reads of the unit it consumed, a slice of VALU work.
+struct MxNoTrace {
+    template <int I>
+    __device__ __forceinline__ void operator()(ic<I>) const {}
+};
+template <class C, int Q0, int NQ, int RT, int NKB, int NPE, int BIAS0, class Reader, class Epi, class Trace = MxNoTrace>
 __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cptr rs_lane, const MxAct<(NKB ? NKB : 1)>& X,
-                                         const half8 (&Ph)[NPE ? NPE : 1], const half8 (&Pl)[NPE ? NPE : 1], Epi&& epi) {
+                                         const half8 (&Ph)[NPE ? NPE : 1], const half8 (&Pl)[NPE ? NPE : 1], Epi&& epi,
+                                         Trace trace = Trace{}) {
     constexpr int GPR = NKB + (NPE ? 1 : 0);
     typedef __attribute__((address_space(3))) const float4v* lds_f4;
     typedef __attribute__((address_space(3))) const unsigned short* lds_u16;
-    float4v acc[2];
-    float4v bias[2];
+    float4v accm[2], accc[2];
     int rs[2] = {0, 0};
-    bias[0] = *(lds_f4)(bias_lane + BIAS0 * 4);
+    accm[0] = *(lds_f4)(bias_lane + BIAS0 * 4);
     if constexpr (NKB > 0) rs[0] = *(lds_u16)(rs_lane + BIAS0 * 2);
+#ifdef TGTC_MX_X_NOFENCE
+    auto fence = [] {};
+#else
+    auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+#endif
     static_for<RT>([&](auto rt_) {
         constexpr int rt = decltype(rt_)::value;
         constexpr int cur = rt & 1;
-        acc[cur] = bias[cur];
+        if constexpr (NKB > 0) accc[cur] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
         static_for<GPR>([&](auto gi_) {
             constexpr int gi = decltype(gi_)::value;
-            const auto& s = rd.template use<Q0 + rt * GPR + gi, NQ>();
-            if constexpr (gi == 0 && rt + 1 < RT) {
-                bias[cur ^ 1] = *(lds_f4)(bias_lane + (BIAS0 + 16 * (rt + 1)) * 4);
-                if constexpr (NKB > 0) rs[cur ^ 1] = *(lds_u16)(rs_lane + (BIAS0 + 16 * (rt + 1)) * 2);
-            }
+            constexpr int Q = Q0 + rt * GPR + gi;
+            // the deferred epilogue of the previous row tile (one half per group), then the next row tile's bias
+            // straight into the accumulator that epilogue has just released
+            auto deferred = [&] {
+#ifdef TGTC_MX_X_NOEPI
+                if constexpr (false) {
+#else
+                if constexpr (rt > 0) {
+#endif
+                    float4v sum = accm[cur ^ 1];
+                    if constexpr (NKB > 0) sum += accc[cur ^ 1];
+                    if constexpr (GPR == 1) {
+                        epi(ic<rt - 1>{}, ic<0>{}, sum);
+                        epi(ic<rt - 1>{}, ic<1>{}, sum);
+                    } else if constexpr (gi < 2) {
+                        epi(ic<rt - 1>{}, ic<gi>{}, sum);
+                    }
+                }
+                if constexpr (gi == (GPR == 1 ? 0 : 1) && rt + 1 < RT) {
+                    accm[cur ^ 1] = *(lds_f4)(bias_lane + (BIAS0 + 16 * (rt + 1)) * 4);
+                    if constexpr (NKB > 0) rs[cur ^ 1] = *(lds_u16)(rs_lane + (BIAS0 + 16 * (rt + 1)) * 2);
+                }
+            };
+            rd.template acquire<Q, NQ>();
+            trace(ic<rt * GPR + gi>{});
             if constexpr (gi < NKB) {
                 constexpr int kb = gi;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[cur] = mfma16(s.u[k], X.h[4 * kb + k], acc[cur]);
-                const u6v wl6 = {__builtin_bit_cast(u4v, s.u[4])[0], __builtin_bit_cast(u4v, s.u[4])[1],
-                                 __builtin_bit_cast(u4v, s.u[4])[2], __builtin_bit_cast(u4v, s.u[4])[3], s.up[0], s.up[1]};
-                acc[cur] = mfma_fp6<1, 0>(wl6, X.h6[kb], acc[cur], rs[cur], X.sc[kb]);
-                const float wscale = __builtin_bit_cast(float, (rs[cur] & 0xff) << 23);
-                const u6v wh6 = cvt_fp6(s.u[0], s.u[1], s.u[2], s.u[3], wscale);
-                acc[cur] = mfma_fp6<0, 1>(wh6, X.l6[kb], acc[cur], rs[cur], X.sc[kb]);
+                accm[cur] = mfma16(rd.u[0], X.h[4 * kb + 0], accm[cur]);
+                rd.template refill<Q + 1, NQ, 0>();
+                fence();
+#ifndef TGTC_MX_X_NOFP6
+                accc[cur] = mfma_fp6<1, 0>(rd.w6[0], X.h6[kb], accc[cur], rs[cur], X.sc[kb]);
+#endif
+                rd.template refill<Q + 1, NQ, 4>();
+                rd.template refill<Q + 1, NQ, 6>();
+                fence();
+                accm[cur] = mfma16(rd.u[1], X.h[4 * kb + 1], accm[cur]);
+                rd.template refill<Q + 1, NQ, 1>();
+                deferred();  // early in the group: the bias / row-exponent reads it ends with are needed at the next row tile's start
+                fence();
+                accm[cur] = mfma16(rd.u[2], X.h[4 * kb + 2], accm[cur]);
+                rd.template refill<Q + 1, NQ, 2>();
+                fence();
+#ifndef TGTC_MX_X_NOFP6
+                accc[cur] = mfma_fp6<0, 1>(rd.w6[1], X.l6[kb], accc[cur], rs[cur], X.sc[kb]);
+#endif
+                rd.template refill<Q + 1, NQ, 5>();
+                rd.template refill<Q + 1, NQ, 7>();
+                fence();
+                accm[cur] = mfma16(rd.u[3], X.h[4 * kb + 3], accm[cur]);
+                rd.template refill<Q + 1, NQ, 3>();
+                fence();
             } else {
-#pragma unroll
-                for (int k = 0; k < NPE; ++k) {
-                    acc[cur] = mfma16(s.u[2 * k], Ph[k], acc[cur]);
-                    acc[cur] = mfma16(s.u[2 * k + 1], Ph[k], acc[cur]);
-                    acc[cur] = mfma16(s.u[2 * k], Pl[k], acc[cur]);
-                }
+                static_for<NPE>([&](auto k_) {
+                    constexpr int k = decltype(k_)::value;
+                    accm[cur] = mfma16(rd.u[2 * k], Ph[k], accm[cur]);
+                    if constexpr (NKB > 0) accc[cur] = mfma16(rd.u[2 * k + 1], Ph[k], accc[cur]);
+                    else accm[cur] = mfma16(rd.u[2 * k + 1], Ph[k], accm[cur]);
+                    accm[cur] = mfma16(rd.u[2 * k], Pl[k], accm[cur]);
+                    rd.template refill<Q + 1, NQ, 2 * k>();
+                    rd.template refill<Q + 1, NQ, 2 * k + 1>();
+                    fence();
+                });
+                rd.template refill_from<Q + 1, NQ, 2 * NPE>();
+                deferred();
+                fence();
             }
-            if constexpr (rt > 0) {  // deferred epilogue of the previous row tile, spread over this one's groups
-                if constexpr (GPR == 1) {
-                    epi(ic<rt - 1>{}, ic<0>{}, acc[cur ^ 1]);
-                    epi(ic<rt - 1>{}, ic<1>{}, acc[cur ^ 1]);
-                } else if constexpr (gi < 2) {
-                    epi(ic<rt - 1>{}, ic<gi>{}, acc[cur ^ 1]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
         });
     });
     // hipcc's hazard model gives VALU readers of a v_mfma_scale_f32_16x16x128_f8f6f4 result the wait states of a
     // 4-pass MFMA; on gfx950 hardware that is not enough (stale accumulators were read right behind the last fp6
     // MFMA of a layer).  The deferred epilogues are >= 6 MFMAs behind; only this final one needs the explicit drain.
-    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[(RT - 1) & 1]));
-    epi(ic<RT - 1>{}, ic<0>{}, acc[(RT - 1) & 1]);
-    epi(ic<RT - 1>{}, ic<1>{}, acc[(RT - 1) & 1]);
+    float4v sum = accm[(RT - 1) & 1];
+    if constexpr (NKB > 0) {
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(accc[(RT - 1) & 1]));
+        sum += accc[(RT - 1) & 1];
+    }
+    epi(ic<RT - 1>{}, ic<0>{}, sum);
+    epi(ic<RT - 1>{}, ic<1>{}, sum);
 }
 
 }  // namespace tgtc

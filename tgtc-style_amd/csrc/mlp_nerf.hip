@@ -50,8 +50,7 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES * C::WG_PER_CU / 4) 
     ws.init(streams, smem, wave, lane);
 #pragma unroll
     for (int j = 0; j < kNerfBiasBytes / (C::NWAVES * 1024); ++j)
-        __builtin_amdgcn_global_load_lds(TGTC_GPTR(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16),
-                                         TGTC_LPTR(smem + C::RING_BYTES + (j * C::NWAVES + wave) * 1024), 16, 0, 0);
+        lds_dma16(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16, smem + C::RING_BYTES + (j * C::NWAVES + wave) * 1024);
     stamp(1);
     ws.prologue();
 

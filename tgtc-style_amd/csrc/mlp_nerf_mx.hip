@@ -1,5 +1,6 @@
 // Fused positional encoding + NeRF MLP in TGTC_PREC_FP16_FP6 (see mlp_mx.h for the arithmetic, mlp_nerf.hip for
 // the network: reference models.py:63-117 MLP_style inside :182-223 StyleNerf).
+#define TGTC_ASM_DMA 1  // see mlp_core.h lds_dma16
 #include "mlp_nerf_mx.h"
 
 #include "mlp_layouts.h"
@@ -46,8 +47,7 @@ __global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
     rd.init(streams, smem, wave, lane);
 #pragma unroll
     for (int j = 0; j < kNerfBiasBytes / (C::NWAVES * 1024); ++j)
-        __builtin_amdgcn_global_load_lds(TGTC_GPTR(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16),
-                                         TGTC_LPTR(smem + C::RING_BYTES + (j * C::NWAVES + wave) * 1024), 16, 0, 0);
+        lds_dma16(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16, smem + C::RING_BYTES + (j * C::NWAVES + wave) * 1024);
     stamp(1);
     rd.ring.prologue();
 
@@ -64,6 +64,13 @@ __global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
     // ---- 4. trunk
     MxAct<2> X, Y;
     MxAct<1> none;  // layers without an activation input
+#if defined(TGTC_MX_X_NOCVT) || defined(TGTC_MX_X_NOEPI)
+    for (int i = 0; i < 8; ++i) X.h[i] = Y.h[i] = pe_h[i & 1][0];
+    for (int i = 0; i < 2; ++i) {
+        X.h6[i] = Y.h6[i] = u6v{(unsigned)lane, 1u, 2u, 3u, 4u, 5u}, X.l6[i] = Y.l6[i] = u6v{7u, (unsigned)lane, 2u, 3u, 4u, 5u};
+        X.sc[i] = Y.sc[i] = 0x7470;
+    }
+#endif
     half8 l16[4];
     const half8 nop[1] = {};
     auto to_Y = [&](auto rt_, auto h_, const float4v& acc) { mx_store_act<decltype(rt_)::value, decltype(h_)::value>(acc, Y, l16); };
@@ -74,7 +81,13 @@ __global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
     stamp(4);
     dense_mx<C, T.first[1], NQ, 16, 2, 0, L::bias0(1)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
     stamp(5);
+#ifdef TGTC_MX_TRACE   // diagnostics: stamps 14..31 = the first 18 group starts of layer 2 (s_memtime after acquire)
+    dense_mx<C, T.first[2], NQ, 16, 2, 0, L::bias0(2)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y, [&](auto i_) {
+        if constexpr (decltype(i_)::value < 18) stamp(14 + decltype(i_)::value);
+    });
+#else
     dense_mx<C, T.first[2], NQ, 16, 2, 0, L::bias0(2)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
+#endif
     stamp(6);
     dense_mx<C, T.first[3], NQ, 16, 2, 0, L::bias0(3)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
     stamp(7);
@@ -177,20 +190,26 @@ int nerf_mx_pack(const tgtc_linear* layers, std::vector<char>& bias_region, std:
                 char* base = stream.data() + T.off[qi];
                 for (int lane = 0; lane < 64; ++lane) {
                     const int m = lane & 15, g = lane >> 4, row = 16 * rt + m;
-                    unsigned long long bits[3] = {0, 0, 0};
-                    const float inv = std::ldexp(1.0f, -(E[m] - 12));  // Wl6 scale 2^(E-1-11)
+                    unsigned long long bl[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
+                    const float inv_l = std::ldexp(1.0f, -(E[m] - 12));  // Wl6 scale 2^(E-1-11)
+                    const float inv_h = std::ldexp(1.0f, -(E[m] - 1));   // Wh6 scale 2^(E-1)
+                    auto put = [](unsigned long long (&b)[3], int i, int code) {
+                        const int bit = 6 * i;
+                        b[bit / 64] |= (unsigned long long)code << (bit % 64);
+                        if (bit % 64 > 58) b[bit / 64 + 1] |= (unsigned long long)code >> (64 - bit % 64);
+                    };
                     for (int s = 0; s < 4; ++s)
                         for (int j = 0; j < 8; ++j) {
                             const float w = weight(row, seg_col(*act, 4 * kb + s, g, j));
                             const half_t hi = (half_t)w;
                             std::memcpy(base + s * 1024 + lane * 16 + j * 2, &hi, 2);
-                            const unsigned long long code = (unsigned long long)e2m3_encode((w - (float)hi) * inv);
-                            const int bit = 6 * (8 * s + j);
-                            bits[bit / 64] |= code << (bit % 64);
-                            if (bit % 64 > 58) bits[bit / 64 + 1] |= code >> (64 - bit % 64);
+                            put(bl, 8 * s + j, e2m3_encode((w - (float)hi) * inv_l));
+                            put(bh, 8 * s + j, e2m3_encode((float)hi * inv_h));
                         }
-                    std::memcpy(base + 4096 + lane * 16, &bits[0], 16);
-                    std::memcpy(base + 5120 + lane * 8, &bits[2], 8);
+                    std::memcpy(base + 4096 + lane * 16, &bl[0], 16);
+                    std::memcpy(base + 5120 + lane * 16, &bh[0], 16);
+                    std::memcpy(base + 6144 + lane * 8, &bl[2], 8);
+                    std::memcpy(base + 6656 + lane * 8, &bh[2], 8);
                 }
             }
             if (sh.npe) {

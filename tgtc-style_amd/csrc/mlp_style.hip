@@ -560,6 +560,8 @@ using namespace tgtc;
 extern "C" int tgtc_style_create(const tgtc_linear* concat_layers, int n_concat, const tgtc_linear* style_layers,
                                  int n_style, int precision, tgtc_net** out) {
     TGTC_REQUIRE(out && (concat_layers || style_layers), "style_create: null argument");
+    if (precision == TGTC_PREC_FP16_FP6)
+        return fail(TGTC_ERR_UNSUPPORTED, "style_create: TGTC_PREC_FP16_FP6 is implemented for the NeRF nets only (use FP16X3 or FP16)");
     TGTC_REQUIRE(precision == TGTC_PREC_FP16 || precision == TGTC_PREC_FP16X3, "style_create: unknown precision %d", precision);
     static const int want_c[5][2] = {{256, 95}, {256, 288}, {256, 288}, {256, 288}, {256, 351}};
     static const int want_s[8][2] = {{256, 607}, {256, 288}, {256, 288}, {256, 288}, {256, 351}, {256, 288}, {256, 288}, {3, 288}};

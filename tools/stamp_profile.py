@@ -36,7 +36,7 @@ dt = np.diff(s, axis=2)            # [64,4,13]
 med = np.median(dt.reshape(-1, 13), 0)
 tot = np.median(s[:, :, 13] - s[:, :, 0])
 frags = [0, 0, 0, 0, 32, 128, 128, 128, 128, 160, 128, 128, 8, 204]
-per = NCT * 16 * (1 if prec == "fp16" else 3)
+per = NCT * 16 * {"fp16": 1, "fp16x3": 3, "fp16mx": 1.5}[prec]
 print("precision", prec, "median wave lifetime (stamped part): %.0f cycles" % tot)
 for i in range(13):
     ideal = frags[i + 1] * per
