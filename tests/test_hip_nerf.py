@@ -183,6 +183,21 @@ def test_render_rays_plain_golden(golden, precision, nc, nf):
     assert float((out["rgb_coarse"].cpu() - ref["rgb_coarse"]).abs().max()) <= lim
 
 
+def test_render_mixed_precision(golden):
+    """Precision is a property of each network handle, so the two passes can differ.  The inverse-CDF step amplifies
+    coarse-pass errors, the fine pass does not: coarse fp16x3 + fine fp16mx stays 3x inside the bar on colour AND depth
+    (2.5e-4 / 2.1e-4 measured), while fp16mx in the coarse pass is what costs the depth its 2e-3."""
+    from tgtc_style_amd import rendering
+    g = golden("g8_end_to_end")
+    ro, rd = torch.from_numpy(g["rays_o_128c64f"]).cuda(), torch.from_numpy(g["rays_d_128c64f"]).cuda()
+    r = rendering.RayRenderer(make_nerf(0, "coarse", "fp16x3"), make_nerf(1, "fine", "fp16mx"))
+    out = r.render(ro, rd, 128, 64)
+    e_rgb = float((out["rgb"].cpu() - torch.from_numpy(g["plain_rgb_128c64f"])).abs().max())
+    e_t = float((out["t"].cpu() - torch.from_numpy(g["plain_t_128c64f"])).abs().max())
+    print("coarse fp16x3 + fine fp16mx: rgb", e_rgb, "t", e_t)
+    assert e_rgb <= 1e-3 and e_t <= 1e-3
+
+
 def test_render_adversarial_scene():
     """Stress scene (synth.nerf_state_adversarial): white-noise density, mostly empty space.  The
     coarse->fine chain is ill-conditioned there -- the fp32 reference itself moves by ~6e-4 when

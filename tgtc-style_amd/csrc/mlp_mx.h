@@ -125,9 +125,6 @@ struct MxReader {
     template <int Q, int NQ, int J>
     __device__ __forceinline__ void refill() {
         if constexpr (Q < NQ) {
-#ifdef TGTC_MX_X_NOLDS   // timing experiment: only the first groups are really read
-            if constexpr (Q > 4) return;
-#endif
             if constexpr (J < units(Q)) {
                 if constexpr (J < 4) {
                     u[J] = read16<T.off[Q] + 1024 * J>();
@@ -201,11 +198,7 @@ __device__ __forceinline__ void mx_store_act(const float4v& acc, MxAct<NKB>& y, 
         y.h[ks][e0 + r] = h;
         l16[ks & 3][e0 + r] = (half_t)((v - (float)h) * 2048.0f);
     }
-#ifdef TGTC_MX_X_NOCVT  // timing experiment: no block conversion
-    if constexpr (false) {
-#else
     if constexpr ((RT & 7) == 7 && HALF == 1) {
-#endif
         constexpr int kb = RT / 8;
         half8 m = __builtin_elementwise_max(__builtin_elementwise_max(y.h[4 * kb], y.h[4 * kb + 1]),
                                             __builtin_elementwise_max(y.h[4 * kb + 2], y.h[4 * kb + 3]));
@@ -245,11 +238,7 @@ __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cpt
     int rs[2] = {0, 0};
     accm[0] = *(lds_f4)(bias_lane + BIAS0 * 4);
     if constexpr (NKB > 0) rs[0] = *(lds_u16)(rs_lane + BIAS0 * 2);
-#ifdef TGTC_MX_X_NOFENCE
-    auto fence = [] {};
-#else
     auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
-#endif
     static_for<RT>([&](auto rt_) {
         constexpr int rt = decltype(rt_)::value;
         constexpr int cur = rt & 1;
@@ -260,11 +249,7 @@ __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cpt
             // the deferred epilogue of the previous row tile (one half per group), then the next row tile's bias
             // straight into the accumulator that epilogue has just released
             auto deferred = [&] {
-#ifdef TGTC_MX_X_NOEPI
-                if constexpr (false) {
-#else
                 if constexpr (rt > 0) {
-#endif
                     float4v sum = accm[cur ^ 1];
                     if constexpr (NKB > 0) sum += accc[cur ^ 1];
                     if constexpr (GPR == 1) {
@@ -286,9 +271,7 @@ __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cpt
                 accm[cur] = mfma16(rd.u[0], X.h[4 * kb + 0], accm[cur]);
                 rd.template refill<Q + 1, NQ, 0>();
                 fence();
-#ifndef TGTC_MX_X_NOFP6
                 accc[cur] = mfma_fp6<1, 0>(rd.w6[0], X.h6[kb], accc[cur], rs[cur], X.sc[kb]);
-#endif
                 rd.template refill<Q + 1, NQ, 4>();
                 rd.template refill<Q + 1, NQ, 6>();
                 fence();
@@ -299,9 +282,7 @@ __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cpt
                 accm[cur] = mfma16(rd.u[2], X.h[4 * kb + 2], accm[cur]);
                 rd.template refill<Q + 1, NQ, 2>();
                 fence();
-#ifndef TGTC_MX_X_NOFP6
                 accc[cur] = mfma_fp6<0, 1>(rd.w6[1], X.l6[kb], accc[cur], rs[cur], X.sc[kb]);
-#endif
                 rd.template refill<Q + 1, NQ, 5>();
                 rd.template refill<Q + 1, NQ, 7>();
                 fence();

@@ -28,14 +28,6 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES * C::WG_PER_CU / 4) 
             a.stamps[((size_t)blockIdx.x * C::NWAVES + wave) * 32 + i] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
-#ifdef TGTC_STAGGER
-    // two co-resident workgroups per CU run the same program: delay the second dispatch round by ~half a pass once,
-    // so that one workgroup's prologue / head layers overlap the other's dense layers from then on
-    if (C::WG_PER_CU == 2 && blockIdx.x >= 256 && blockIdx.x < 512) {
-#pragma unroll 1
-        for (int i = 0; i < TGTC_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
 
     // ---- 1. inputs (ordinary loads first: once LDS-DMA is in flight hipcc drains vmcnt(0) for them)
     double pos[NCT][3], dir[NCT][3];

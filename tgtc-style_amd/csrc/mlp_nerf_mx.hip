@@ -64,13 +64,6 @@ __global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
     // ---- 4. trunk
     MxAct<2> X, Y;
     MxAct<1> none;  // layers without an activation input
-#if defined(TGTC_MX_X_NOCVT) || defined(TGTC_MX_X_NOEPI)
-    for (int i = 0; i < 8; ++i) X.h[i] = Y.h[i] = pe_h[i & 1][0];
-    for (int i = 0; i < 2; ++i) {
-        X.h6[i] = Y.h6[i] = u6v{(unsigned)lane, 1u, 2u, 3u, 4u, 5u}, X.l6[i] = Y.l6[i] = u6v{7u, (unsigned)lane, 2u, 3u, 4u, 5u};
-        X.sc[i] = Y.sc[i] = 0x7470;
-    }
-#endif
     half8 l16[4];
     const half8 nop[1] = {};
     auto to_Y = [&](auto rt_, auto h_, const float4v& acc) { mx_store_act<decltype(rt_)::value, decltype(h_)::value>(acc, Y, l16); };
@@ -81,13 +74,7 @@ __global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
     stamp(4);
     dense_mx<C, T.first[1], NQ, 16, 2, 0, L::bias0(1)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
     stamp(5);
-#ifdef TGTC_MX_TRACE   // diagnostics: stamps 14..31 = the first 18 group starts of layer 2 (s_memtime after acquire)
-    dense_mx<C, T.first[2], NQ, 16, 2, 0, L::bias0(2)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y, [&](auto i_) {
-        if constexpr (decltype(i_)::value < 18) stamp(14 + decltype(i_)::value);
-    });
-#else
     dense_mx<C, T.first[2], NQ, 16, 2, 0, L::bias0(2)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
-#endif
     stamp(6);
     dense_mx<C, T.first[3], NQ, 16, 2, 0, L::bias0(3)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
     stamp(7);

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Development probe: end-to-end error of the plain render for every (coarse precision, fine precision) pair, against
+the oracle on 1024 rays of a fern-shaped frame and against the reference's own renders (golden g8)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from oracle import fields
+from tgtc_style_amd import hip, synth, utils, rendering, models
+
+t = lambda sd: {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+def net(seed, mode, prec):
+    a = type("A", (bench.NetArgs,), {"precision": prec})
+    m = models.StyleNerf(a, mode=mode)
+    m.load_state_dict(t(synth.nerf_state(seed)))
+    return m.cuda()
+H = W = 400
+ro, rd = utils.gen_rays(H, W, synth.fern_intrinsics(H, W), synth.spiral_pose(3))
+idx = torch.arange(0, H * W, H * W // 1024)[:1024].cuda()
+ro, rd = ro[idx].contiguous(), rd[idx].contiguous()
+ref = fields.render_plain(t(synth.nerf_state(0)), t(synth.nerf_state(1)), ro.cpu(), rd.cpu(), 128, 64)
+g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "g8_end_to_end.npz"))
+gro, grd = torch.from_numpy(g["rays_o_128c64f"]).cuda(), torch.from_numpy(g["rays_d_128c64f"]).cuda()
+for pc in ("fp16x3", "fp16mx", "fp16"):
+    for pf in ("fp16x3", "fp16mx", "fp16"):
+        r = rendering.RayRenderer(net(0, "coarse", pc), net(1, "fine", pf))
+        out = r.render(ro, rd, 128, 64)
+        e1 = float((out["rgb"].cpu() - ref["rgb_fine"]).abs().max()); t1 = float((out["t"].cpu() - ref["t_fine"]).abs().max())
+        o2 = r.render(gro, grd, 128, 64)
+        e2 = float((o2["rgb"].cpu() - torch.from_numpy(g["plain_rgb_128c64f"])).abs().max())
+        t2 = float((o2["t"].cpu() - torch.from_numpy(g["plain_t_128c64f"])).abs().max())
+        print("coarse %-7s fine %-7s | 1024 rays vs oracle: rgb %.2e t %.2e | golden 64 rays: rgb %.2e t %.2e" % (pc, pf, e1, t1, e2, t2))
