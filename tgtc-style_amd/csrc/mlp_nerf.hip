@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES * C::WG_PER_CU / 4) 
 }
 
 // ------------------------------------------------------------------------------------------------ host
+#ifndef TGTC_TU_FP16_ONLY
 std::vector<LayerSpec> nerf_specs(const tgtc_linear* l) {
     std::vector<LayerSpec> v;
     auto add = [&](int idx, std::vector<Seg> segs) {
@@ -153,13 +154,22 @@ std::vector<LayerSpec> nerf_specs(const tgtc_linear* l) {
     return v;
 }
 
+#endif
+
 // Measurement hook (bench.py): HIP events recorded on the launch stream around the next FULL / sigma-only
 // launch, so the kernel's duration is measured live inside the timed region.  Thread-local, one-shot.
-static thread_local unsigned long long* g_stamps = nullptr;  // diagnostics, see tgtc_debug_set_stamps
-static thread_local hipEvent_t g_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+// (the fp16 kernels are compiled in a translation unit of their own -- same source, -DTGTC_TU_FP16_ONLY -- to halve
+// the build time; these two are shared with it)
+#ifdef TGTC_TU_FP16_ONLY
+extern thread_local unsigned long long* g_stamps;
+extern thread_local hipEvent_t g_ev[2][2];
+#else
+thread_local unsigned long long* g_stamps = nullptr;  // diagnostics, see tgtc_debug_set_stamps
+thread_local hipEvent_t g_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+#endif
 
 template <class C, int IN_MODE, bool FULL>
-static int launch_nerf(const NerfArgs& a, hipStream_t st) {
+int launch_nerf(const NerfArgs& a, hipStream_t st) {
     const long long nwg = (a.M + C::SAMPLES_PER_WG - 1) / C::SAMPLES_PER_WG;
     if (a.M >= 0x7fffffffLL) return fail(TGTC_ERR_UNSUPPORTED, "nerf: too many samples in one launch (%lld)", a.M);
     hipEvent_t* ev = g_ev[FULL ? 1 : 0];
@@ -177,6 +187,17 @@ static int launch_nerf(const NerfArgs& a, hipStream_t st) {
 // which is what the 4-wave / 4-column-tile geometry (470-510 registers) ran into.
 using CfgFast = MlpCfg<8, 2, false, 4>;
 using CfgExact = MlpCfg<8, 1, true, 4>;
+
+#define TGTC_NERF_FP16_INSTANCES(PREFIX)                                           \
+    PREFIX template int launch_nerf<CfgFast, IN_RAYS, false>(const NerfArgs&, hipStream_t); \
+    PREFIX template int launch_nerf<CfgFast, IN_RAYS, true>(const NerfArgs&, hipStream_t);  \
+    PREFIX template int launch_nerf<CfgFast, IN_PTS, true>(const NerfArgs&, hipStream_t);   \
+    PREFIX template int launch_nerf<CfgFast, IN_ENC, true>(const NerfArgs&, hipStream_t);
+#ifdef TGTC_TU_FP16_ONLY
+TGTC_NERF_FP16_INSTANCES()
+}  // namespace tgtc
+#else
+TGTC_NERF_FP16_INSTANCES(extern)
 
 template <int IN_MODE, bool FULL>
 static int dispatch_nerf(const tgtc_net* net, NerfArgs& a, hipStream_t st) {
@@ -321,3 +342,4 @@ extern "C" int tgtc_nerf_forward_rays(const tgtc_net* net, const double* rays_o,
     TGTC_REQUIRE(rays_o && rays_d && ts && (rgb || sigma), "nerf_forward_rays: null input");
     return nerf_forward_rays_impl(net, rays_o, rays_d, ts, R, N, rgb, sigma, as_stream(stream));
 }
+#endif  // TGTC_TU_FP16_ONLY

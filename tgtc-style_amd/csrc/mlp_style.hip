@@ -524,6 +524,30 @@ using CfgExact = MlpCfg<8, 1, true, 4>;
 using CfgFastNarrow = MlpCfg<4, 2, false, 4>;   // granular style MLP: 512 extra input features live in registers
 using CfgExactNarrow = MlpCfg<4, 1, true, 4>;
 
+// Launch wrappers.  The fp16 instances are compiled in a translation unit of their own (this source with
+// -DTGTC_TU_FP16_ONLY) so that the two big kernel sets build in parallel.
+template <class C>
+void launch_styled_rays(unsigned grid, const StyledArgs& a, hipStream_t st) {
+    styled_rays_kernel<C><<<grid, C::NWAVES * 64, 0, st>>>(a);
+}
+template <class C>
+void launch_concat(const ConcatArgs& a, hipStream_t st) {
+    concat_kernel<C><<<(unsigned)((a.M + C::SAMPLES_PER_WG - 1) / C::SAMPLES_PER_WG), C::NWAVES * 64, 0, st>>>(a);
+}
+template <class C>
+void launch_style(const StyleArgs& a, hipStream_t st) {
+    style_kernel<C><<<(unsigned)((a.M + C::SAMPLES_PER_WG - 1) / C::SAMPLES_PER_WG), C::NWAVES * 64, 0, st>>>(a);
+}
+#define TGTC_STYLE_FP16_INSTANCES(PREFIX)                                                        \
+    PREFIX template void launch_styled_rays<CfgFast>(unsigned, const StyledArgs&, hipStream_t); \
+    PREFIX template void launch_concat<CfgFast>(const ConcatArgs&, hipStream_t);                \
+    PREFIX template void launch_style<CfgFastNarrow>(const StyleArgs&, hipStream_t);
+#ifdef TGTC_TU_FP16_ONLY
+TGTC_STYLE_FP16_INSTANCES()
+}  // namespace tgtc
+#else
+TGTC_STYLE_FP16_INSTANCES(extern)
+
 int styled_forward_rays_impl(const tgtc_net* nerf, const tgtc_net* style, const double* rays_o, const double* rays_d,
                              const float* ts, const float* z, int64_t R, int N, float* rgb, float* sigma,
                              hipStream_t st) {
@@ -535,19 +559,12 @@ int styled_forward_rays_impl(const tgtc_net* nerf, const tgtc_net* style, const 
     a.style_stream = style->dev + style->stream2_off, a.stash = style->dev + style->stash_off;
     a.M = R * (int64_t)N, a.N = N, a.rays_o = rays_o, a.rays_d = rays_d, a.ts = ts, a.z = z, a.rgb = rgb, a.sigma = sigma;
     if (a.M >= 0x7fffffffLL) return fail(TGTC_ERR_UNSUPPORTED, "styled_forward_rays: too many samples in one launch");
-#ifdef TGTC_DEV_STYLED_FAST_ONLY
-    if (nerf->precision != TGTC_PREC_FP16) return fail(TGTC_ERR_UNSUPPORTED, "development build");
-#endif
     if (nerf->precision == TGTC_PREC_FP16) {
         const long long tiles = (a.M + CfgFast::SAMPLES_PER_WG - 1) / CfgFast::SAMPLES_PER_WG;
-        const unsigned grid = (unsigned)(tiles < style->n_wg ? tiles : style->n_wg);
-        styled_rays_kernel<CfgFast><<<grid, CfgFast::NWAVES * 64, 0, st>>>(a);
+        launch_styled_rays<CfgFast>((unsigned)(tiles < style->n_wg ? tiles : style->n_wg), a, st);
     } else {
-#ifndef TGTC_DEV_STYLED_FAST_ONLY
         const long long tiles = (a.M + CfgExact::SAMPLES_PER_WG - 1) / CfgExact::SAMPLES_PER_WG;
-        const unsigned grid = (unsigned)(tiles < style->n_wg ? tiles : style->n_wg);
-        styled_rays_kernel<CfgExact><<<grid, CfgExact::NWAVES * 64, 0, st>>>(a);
-#endif
+        launch_styled_rays<CfgExact>((unsigned)(tiles < style->n_wg ? tiles : style->n_wg), a, st);
     }
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;
@@ -627,17 +644,14 @@ extern "C" int tgtc_style_create(const tgtc_linear* concat_layers, int n_concat,
     return TGTC_OK;
 }
 
-#ifndef TGTC_DEV_STYLED_FAST_ONLY
 extern "C" int tgtc_concat_mlp_forward(const tgtc_net* style, const float* x, const float* latent, int64_t M,
                                        float* concat_features, void* stream) {
     TGTC_REQUIRE(style && style->kind == 1 && M >= 0, "concat_mlp_forward: bad argument");
     if (M == 0) return TGTC_OK;
     TGTC_REQUIRE(x && latent && concat_features, "concat_mlp_forward: null pointer");
     ConcatArgs a{style->dev, style->dev + style->bias_bytes, M, x, latent, concat_features};
-    if (style->precision == TGTC_PREC_FP16)
-        concat_kernel<CfgFast><<<(unsigned)((M + CfgFast::SAMPLES_PER_WG - 1) / CfgFast::SAMPLES_PER_WG), CfgFast::NWAVES * 64, 0, as_stream(stream)>>>(a);
-    else
-        concat_kernel<CfgExact><<<(unsigned)((M + CfgExact::SAMPLES_PER_WG - 1) / CfgExact::SAMPLES_PER_WG), CfgExact::NWAVES * 64, 0, as_stream(stream)>>>(a);
+    if (style->precision == TGTC_PREC_FP16) launch_concat<CfgFast>(a, as_stream(stream));
+    else launch_concat<CfgExact>(a, as_stream(stream));
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;
 }
@@ -648,15 +662,11 @@ extern "C" int tgtc_style_mlp_forward(const tgtc_net* style, const float* x, con
     if (M == 0) return TGTC_OK;
     TGTC_REQUIRE(x && concated && latent && rgb, "style_mlp_forward: null pointer");
     StyleArgs a{style->dev, style->dev + style->stream2_off, M, x, concated, latent, rgb};
-    if (style->precision == TGTC_PREC_FP16)
-        style_kernel<CfgFastNarrow><<<(unsigned)((M + CfgFastNarrow::SAMPLES_PER_WG - 1) / CfgFastNarrow::SAMPLES_PER_WG), 256, 0, as_stream(stream)>>>(a);
-    else
-        style_kernel<CfgExactNarrow><<<(unsigned)((M + CfgExactNarrow::SAMPLES_PER_WG - 1) / CfgExactNarrow::SAMPLES_PER_WG), 256, 0, as_stream(stream)>>>(a);
+    if (style->precision == TGTC_PREC_FP16) launch_style<CfgFastNarrow>(a, as_stream(stream));
+    else launch_style<CfgExactNarrow>(a, as_stream(stream));
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;
 }
-
-#endif  // TGTC_DEV_STYLED_FAST_ONLY
 
 extern "C" int tgtc_styled_forward_rays(const tgtc_net* nerf, const tgtc_net* style, const double* rays_o,
                                         const double* rays_d, const float* ts, const float* z, int64_t R, int N,
@@ -666,3 +676,4 @@ extern "C" int tgtc_styled_forward_rays(const tgtc_net* nerf, const tgtc_net* st
     TGTC_REQUIRE(rays_o && rays_d && ts && z && rgb, "styled_forward_rays: null pointer");
     return styled_forward_rays_impl(nerf, style, rays_o, rays_d, ts, z, R, N, rgb, sigma, as_stream(stream));
 }
+#endif  // TGTC_TU_FP16_ONLY
