@@ -130,6 +130,16 @@ int tgtc_render_rays_plain(const tgtc_net* coarse, const tgtc_net* fine, const d
 int tgtc_latents_forward(const float* latents, const float* mu, int S, int F, int D, const int64_t* style_ids,
                          const int64_t* frame_ids, int64_t R, float sigma_scale, int tile7, float* out, void* stream);
 
+/* ------------------------------------------------------------------ a13 (image epilogue)
+ * rendering.py:66-71 (cal_geometry), :202-206 (render_style), :358-361 (render_train_style): what the drivers do to
+ * every finished frame before imageio.imwrite -- per-frame sv_t = (t - min t) / (max t - min t + eps), then
+ * np.array(x * 255, np.int32) and to8b = np.uint8 cast (utils.py:463; wraps modulo 256, e.g. 1.0039 -> 0).
+ * rgb float [frames*pixels,3], t float [frames*pixels] -> rgb8 uint8 [frames*pixels,3], depth8 uint8 [frames*pixels]
+ * (either output may be NULL).  eps = 1e-7 for cal_geometry / render_style, 0 for render_train_style (whose depth
+ * image is the same plane written three times, host side).  Only 4 bytes per ray cross PCIe afterwards. */
+int tgtc_image_epilogue(const float* rgb, const float* t, int64_t frames, int64_t pixels, float eps, unsigned char* rgb8,
+                        unsigned char* depth8, void* stream);
+
 /* ------------------------------------------------------------------ a10+a11: the two style MLPs
  * models.py:120-147 StyleMLP_before_concat (5 linears: 95,288,288,288,351 -> 256) and
  * models.py:149-180 StyleMLP_Wild_multilayers (8 linears: 607,288,288,288,351,288,288 -> 256, 288 -> 3). */

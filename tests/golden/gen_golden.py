@@ -417,8 +417,39 @@ def g9_style2d():
     save("g9_style2d", **out)
 
 
+# ----------------------------------------------------------------------------- G10 image epilogue
+def g10_image():
+    """What rendering.cal_geometry hands to imageio.imwrite for each finished frame (rendering.py:66-73): the inert
+    imageio placeholder is given a recording imwrite for the duration of the call."""
+    import imageio  # the placeholder registered by ref_shim.install()
+    a = type("A", (Args,), {"N_samples": 64, "N_samples_fine": 64})
+    h, w, frames = 6, 8, 3
+    ro, rd = test_rays(frames * h * w, 1010)
+    coarse, fine = make_nerf(0, "coarse", a), make_nerf(1, "fine", a)
+    fwd_c = ref_utils.batchify(lambda **kw: coarse(**kw), 32)
+    fwd_f = ref_utils.batchify(lambda **kw: fine(**kw), 32)
+    ds = _FakeDataset(h, w, 0., 1., np.tile(np.eye(4, dtype=np.float32)[None], (frames, 1, 1)))
+    batches = [{"rays_o": torch.from_numpy(ro[i:i + 40]), "rays_d": torch.from_numpy(rd[i:i + 40])}
+               for i in range(0, frames * h * w, 40)]   # 40 does not divide a frame: frames complete mid-batch
+    written = []
+    imageio.imwrite = lambda path, arr: written.append((os.path.basename(path), np.array(arr)))
+    try:
+        with tempfile.TemporaryDirectory() as tmp, torch.no_grad():
+            rgb_map, t_map = ref_rendering.cal_geometry(
+                model_forward=fwd_c, samp_func=ref_utils.sampling_pts_uniform, dataloader=_FakeLoader(ds, batches),
+                args=a, device="cpu", sv_path=tmp, model_forward_fine=fwd_f,
+                samp_func_fine=ref_utils.sampling_pts_fine_torch)
+    finally:
+        del imageio.imwrite
+    names = [n for n, _ in written]
+    assert names == [x for i in range(frames) for x in ("rgb_%05d.png" % i, "depth_%05d.png" % i)], names
+    save("g10_image", rgb=rgb_map.reshape(-1, 3), t=t_map.reshape(-1), frames=np.int64(frames), h=np.int64(h), w=np.int64(w),
+         rgb8=np.stack([arr for n, arr in written if n.startswith("rgb")]),
+         depth8=np.stack([arr for n, arr in written if n.startswith("depth")]))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1_rays, g2_coarse, g3_embed, g4_nerf, g5_composite, g6_fine, g7_style, g8_end_to_end, g9_style2d):
+    for fn in (g1_rays, g2_coarse, g3_embed, g4_nerf, g5_composite, g6_fine, g7_style, g8_end_to_end, g9_style2d, g10_image):
         if not only or fn.__name__.split("_")[0] in only:
             fn()

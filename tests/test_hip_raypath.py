@@ -175,3 +175,37 @@ def test_latents_golden(golden):
         assert maxdiff(out, g["latents_s%g" % sc]) <= 1e-7     # one fused multiply-add of difference at most
     with pytest.raises(IndexError):
         lat(style_ids=torch.tensor([1]), frame_ids=torch.tensor([7 * 40]), type="llff")
+
+
+def test_image_epilogue_golden_and_edges(golden):
+    """a13 image epilogue (rendering.py:66-71 / :202-207 / :358-361): uint8 images bit-identical to what the reference
+    wrote (g10), to the oracle on full-size frames, and on the edge cases of the numpy casts."""
+    from oracle import image
+    from tgtc_style_amd import utils
+    g = golden("g10_image")
+    frames = int(g["frames"])
+    rgb8, depth8 = utils.frames_to_uint8(dev(g["rgb"]), dev(g["t"]), frames)
+    assert np.array_equal(rgb8.cpu().numpy().reshape(g["rgb8"].shape), g["rgb8"])
+    assert np.array_equal(depth8.cpu().numpy().reshape(g["depth8"].shape), g["depth8"])
+    # BASELINE frame size, several frames, both eps conventions
+    rng = np.random.default_rng(21)
+    rgb = rng.uniform(0, 1, (3 * 160000, 3)).astype(np.float32)
+    t = rng.uniform(0.1, 0.9, 3 * 160000).astype(np.float32)
+    for eps in (1e-7, 0.0):
+        a, b = utils.frames_to_uint8(dev(rgb), dev(t), 3, eps)
+        ra, rb = image.frames_to_uint8(rgb, t, 3, eps)
+        assert np.array_equal(a.cpu().numpy(), ra) and np.array_equal(b.cpu().numpy(), rb)
+    # edges: colours a hair above 1 wrap to 0 (256 -> uint8), exact 1.0 -> 255, a constant depth plane -> 0 / eps = 0
+    # (and 0/0 = NaN -> 0 without eps), a single pixel per frame, either output alone
+    rgb = np.array([[1.0, 1.004, 0.0], [0.999999, 0.5, 1.0039216]], np.float32)
+    t = np.array([0.25, 0.25], np.float32)
+    for eps in (1e-7, 0.0):
+        for frames in (1, 2):
+            a, b = utils.frames_to_uint8(dev(rgb), dev(t), frames, eps)
+            ra, rb = image.frames_to_uint8(rgb, t, frames, eps)
+            assert np.array_equal(a.cpu().numpy(), ra) and np.array_equal(b.cpu().numpy(), rb), (eps, frames)
+    assert ra[0, 0].tolist() == [255, 0, 0]
+    only_rgb, none = utils.frames_to_uint8(dev(rgb), None, 1)
+    assert none is None and np.array_equal(only_rgb.cpu().numpy(), image.frames_to_uint8(rgb, t, 1)[0])
+    none, only_t = utils.frames_to_uint8(None, dev(np.array([0.5, 0.1, 0.9], np.float32)), 1)
+    assert none is None and only_t.cpu().numpy().tolist() == [[127, 0, 254]]

@@ -181,3 +181,14 @@ def test_g9_style2d(golden):
     close(out["ics"], g["st_ics"], 2e-4)
     close(out["image"], g["st_image"], 2e-4)
     close(out["style_feature"], g["st_feature"], 2e-5)
+
+
+def test_g10_image_epilogue(golden):
+    """oracle.image vs the arrays the reference's cal_geometry handed to imageio.imwrite (integer work: bit exact)."""
+    from oracle import image
+    g = golden("g10_image")
+    frames, h, w = int(g["frames"]), int(g["h"]), int(g["w"])
+    rgb8, depth8 = image.frames_to_uint8(g["rgb"], g["t"], frames)
+    assert rgb8.dtype == np.uint8 and depth8.dtype == np.uint8
+    assert np.array_equal(rgb8.reshape(frames, h, w, 3), g["rgb8"])
+    assert np.array_equal(depth8.reshape(frames, h, w), g["depth8"])

@@ -409,6 +409,50 @@ extern "C" int tgtc_sample_fine(const double* rays_o, const double* rays_d, cons
     return launch_sample_fine(rays_o, rays_d, ts, weights, R, N, n_fine, pts_out, ts_out, as_stream(stream));
 }
 
+// ------------------------------------------------------------------------------------------------ image epilogue
+// One workgroup per frame finds min / max of the depth (exact: min/max are order independent), then the same
+// workgroup converts its frame.  numpy semantics: float32 arithmetic throughout (x*255, the division), float ->
+// int32 truncates toward zero, int32 -> uint8 keeps the low byte.
+__global__ void __launch_bounds__(1024) image_epilogue_kernel(const float* __restrict__ rgb, const float* __restrict__ t,
+                                                             long long pixels, float eps, unsigned char* __restrict__ rgb8,
+                                                             unsigned char* __restrict__ depth8) {
+    __shared__ float s_min[16], s_max[16];
+    const long long base = (long long)blockIdx.x * pixels;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (depth8) {
+        float lo = __builtin_inff(), hi = -__builtin_inff();
+        for (long long i = tid; i < pixels; i += 1024) {
+            const float v = t[base + i];
+            lo = fminf(lo, v), hi = fmaxf(hi, v);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lo = fminf(lo, __shfl_xor(lo, o)), hi = fmaxf(hi, __shfl_xor(hi, o));
+        if (lane == 0) s_min[wave] = lo, s_max[wave] = hi;
+        __syncthreads();
+        lo = s_min[0], hi = s_max[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) lo = fminf(lo, s_min[w]), hi = fmaxf(hi, s_max[w]);
+        const float den = __fadd_rn(__fsub_rn(hi, lo), eps);
+        for (long long i = tid; i < pixels; i += 1024) {
+            const float v = __fdiv_rn(__fsub_rn(t[base + i], lo), den);   // IEEE division, as numpy
+            depth8[base + i] = (unsigned char)(int)__fmul_rn(v, 255.0f);
+        }
+    }
+    if (rgb8) {
+        for (long long i = tid; i < pixels * 3; i += 1024) rgb8[base * 3 + i] = (unsigned char)(int)__fmul_rn(rgb[base * 3 + i], 255.0f);
+    }
+}
+
+extern "C" int tgtc_image_epilogue(const float* rgb, const float* t, int64_t frames, int64_t pixels, float eps,
+                                   unsigned char* rgb8, unsigned char* depth8, void* stream) {
+    TGTC_REQUIRE(frames >= 0 && pixels >= 0 && frames < (1LL << 31), "image_epilogue: bad argument");
+    if (frames == 0 || pixels == 0) return TGTC_OK;
+    TGTC_REQUIRE((!rgb8 || rgb) && (!depth8 || t) && (rgb8 || depth8), "image_epilogue: null pointer");
+    image_epilogue_kernel<<<(unsigned)frames, 1024, 0, as_stream(stream)>>>(rgb, t, pixels, eps, rgb8, depth8);
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
+}
+
 extern "C" int tgtc_latents_forward(const float* latents, const float* mu, int S, int F, int D,
                                     const int64_t* style_ids, const int64_t* frame_ids, int64_t R, float sigma_scale,
                                     int tile7, float* out, void* stream) {

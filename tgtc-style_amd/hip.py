@@ -51,6 +51,7 @@ _SIGNATURES = {
     "tgtc_render_workspace_bytes": [c_int64, c_int, c_int],
     "tgtc_render_rays_plain": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float,
                                c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "tgtc_image_epilogue": [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p],
     "tgtc_latents_forward": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_float, c_int,
                              c_void_p, c_void_p],
 }

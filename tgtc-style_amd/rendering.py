@@ -90,11 +90,24 @@ def _require_fine(args):
                          "(rendering.py:186; train_tgtcs.py:184)")
 
 
-def _write_depth_rgb(sv_path, rgb, t, h, w, rgb_name, depth_name):
-    """rendering.py:202-217: per-image min-max depth normalisation, x255, int32, uint8 cast."""
-    sv_t = (t - t.min()) / (t.max() - t.min() + 1e-7)
-    _save_png(os.path.join(sv_path, rgb_name), np.array(rgb.reshape(h, w, 3) * 255, np.int32))
-    _save_png(os.path.join(sv_path, depth_name), np.array(sv_t.reshape(h, w) * 255, np.int32))
+def _write_depth_rgb(sv_path, rgb, t, h, w, rgb_name, depth_name, eps=1e-7, depth_channels=1):
+    """rendering.py:202-217 (:358-361 for eps = 0, three depth channels): per-image min-max depth normalisation, x255,
+    int32, uint8 cast.  CUDA tensors take the device epilogue (only the 8-bit images cross PCIe); numpy arrays the
+    reference's own host arithmetic."""
+    if isinstance(rgb, torch.Tensor) and rgb.is_cuda:
+        from . import utils
+        rgb8, depth8 = utils.frames_to_uint8(rgb, t, 1, eps)
+        rgb8, depth8 = rgb8.cpu().numpy().reshape(h, w, 3), depth8.cpu().numpy().reshape(h, w)
+    else:
+        rgb, t = np.asarray(rgb, np.float32), np.asarray(t, np.float32)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            sv_t = (t - t.min()) / ((t.max() - t.min() + eps) if eps else (t.max() - t.min()))
+            rgb8 = np.array(rgb.reshape(h, w, 3) * 255, np.int32).astype(np.uint8)
+            depth8 = np.array(sv_t.reshape(h, w) * 255, np.int32).astype(np.uint8)
+    if depth_channels == 3:
+        depth8 = np.broadcast_to(depth8[..., None], [h, w, 3])
+    _save_png(os.path.join(sv_path, rgb_name), rgb8)
+    _save_png(os.path.join(sv_path, depth_name), depth8)
 
 
 def cal_geometry(model_forward, samp_func, dataloader, args, device, sv_path=None, model_forward_fine=None,
@@ -191,13 +204,13 @@ def render_style(model_forward, samp_func, style_forward, concat_style_forward, 
     ds.mode = 'valid_style'
     frame_num, h, w = ds.cps_valid.shape[0], ds.h, ds.w
     res = h * w
-    pend_rgb, pend_t, image_no = np.zeros([0, 3], np.float32), np.zeros([0], np.float32), 0
+    pend_rgb, pend_t, image_no = torch.zeros([0, 3], device=device), torch.zeros([0], device=device), 0
     for batch in dataloader:
         b = _to_device(batch, device)
         rgb_f, t_f = _styled_batch(b, args, ds, samp_func, model_forward, style_forward, concat_style_forward,
                                    latents_model_1, model_forward_fine, samp_func_fine, renderer)
-        pend_rgb = np.concatenate([pend_rgb, rgb_f.detach().cpu().numpy()], 0)
-        pend_t = np.concatenate([pend_t, t_f.detach().cpu().numpy()], 0)
+        pend_rgb = torch.cat([pend_rgb, rgb_f.detach().float()], 0)      # stays on the device until a frame is complete
+        pend_t = torch.cat([pend_t, t_f.detach().float()], 0)
         while pend_rgb.shape[0] >= res:
             if sv_path is not None:
                 # file numbering: images are consecutive (style, frame) pairs (rendering.py:209-218)
@@ -206,7 +219,7 @@ def render_style(model_forward, samp_func, style_forward, concat_style_forward, 
                                  'style_%05d_fine_depth_%05d.png' % (image_no // frame_num, image_no % frame_num))
             image_no += 1
             pend_rgb, pend_t = pend_rgb[res:], pend_t[res:]
-    return pend_rgb, pend_t
+    return pend_rgb.cpu().numpy(), pend_t.cpu().numpy()
 
 
 def render_train_style(samp_func, model_forward, style_forward, concat_style_forward, latents_model_1, dataset, args,
@@ -235,16 +248,13 @@ def render_train_style(samp_func, model_forward, style_forward, concat_style_for
             b = _to_device(batch, device)
             rgb_f, t_f = _styled_batch(b, args, dataset, samp_func, model_forward, style_forward, concat_style_forward,
                                        latents_model_1, model_forward_fine, samp_func_fine, renderer)
-            rgbs.append(torch.clamp(rgb_f, 0., 1.).detach().cpu().numpy())
-            ts.append(t_f.detach().cpu().numpy())
+            rgbs.append(torch.clamp(rgb_f, 0., 1.).detach())
+            ts.append(t_f.detach())
         it += 1
         if it == iters_per_image:
             if not exists:
-                rgb = np.concatenate(rgbs, 0).reshape(h, w, 3)
-                t = np.broadcast_to(np.concatenate(ts, 0).reshape(h, w)[..., None], [h, w, 3])
-                t = (t - t.min()) / (t.max() - t.min())
-                _save_png(path, np.array(rgb * 255, np.int32))
-                _save_png(path.replace('_fine_', '_fine_depth_'), np.array(t * 255, np.int32))
+                _write_depth_rgb(sv_path, torch.cat(rgbs, 0), torch.cat(ts, 0), h, w, os.path.basename(path),
+                                 os.path.basename(path).replace('_fine_', '_fine_depth_'), eps=0., depth_channels=3)
             img_count += 1
             it, rgbs, ts = 0, [], []
     return img_count

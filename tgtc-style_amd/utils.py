@@ -108,3 +108,24 @@ def gen_rays(H, W, focal, c2w, first_pixel=0, n=None, pixel_alignment=False, ndc
                                 int(pixel_alignment), int(ndc), float(ndc_near), first_pixel, n, hip.ptr(o),
                                 hip.ptr(d), hip.stream()))
     return o, d
+
+
+def frames_to_uint8(rgb, t, frames, eps=1e-7):
+    """Image epilogue of the render drivers on the device (rendering.py:66-71, :202-207, :358-361; utils.py:463 to8b):
+    per-frame min-max normalised depth and colour as uint8(int32(x * 255)).  rgb [frames*P,3], t [frames*P] float32
+    CUDA tensors -> (uint8 [frames,P,3], uint8 [frames,P]) CUDA tensors; either input may be None."""
+    lib = hip.load()
+    ref = rgb if rgb is not None else t
+    pixels = ref.shape[0] // frames
+    assert ref.is_cuda and ref.shape[0] == frames * pixels
+    rgb8 = depth8 = None
+    if rgb is not None:
+        rgb = rgb.detach().contiguous().float()
+        rgb8 = torch.empty(frames, pixels, 3, dtype=torch.uint8, device=rgb.device)
+    if t is not None:
+        t = t.detach().contiguous().float()
+        depth8 = torch.empty(frames, pixels, dtype=torch.uint8, device=t.device)
+    hip.check(lib.tgtc_image_epilogue(hip.ptr(rgb) if rgb is not None else None, hip.ptr(t) if t is not None else None,
+                                      frames, pixels, float(eps), hip.ptr(rgb8) if rgb8 is not None else None,
+                                      hip.ptr(depth8) if depth8 is not None else None, hip.stream()))
+    return rgb8, depth8
