@@ -37,7 +37,8 @@ PEAK_FP16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
 # HBM bytes of one fine-pass launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
 # WRITE_SIZE collected in separate --pmc runs; FETCH_SIZE calibrated 1:1 on the known 4-B-per-lane depth reads
 # of this kernel, see profiles/r1_pmc_summary.md).  bench.py cannot collect counters itself.
-PMC_TRAFFIC_BYTES = {"fp16x3": (100130.0 + 480000.0) * 1024, "fp16": None}
+PMC_TRAFFIC_BYTES = {"fp16x3": (102733.0 + 480000.0) * 1024, "fp16mx": (99245.0 + 480000.0) * 1024,
+                     "fp16": (85263.0 + 480000.0) * 1024}   # FETCH_SIZE + WRITE_SIZE (KB) of the fine-pass launch, profiles/r1_pmc_summary.md
 
 
 class NetArgs:

@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES * C::WG_PER_CU / 4) 
     long long sidx[NCT];
     nerf_load_samples<NCT, IN_MODE>(a, s_wave, n, pos, dir, sidx);
     half8 pe_h[2][NCT], pe_l[2][NCT], de_h[1][NCT], de_l[1][NCT];
-    if constexpr (IN_MODE == IN_ENC) nerf_load_encoded<NCT, SPLIT, FULL>(a, sidx, g, pe_h, pe_l, de_h, de_l);
+    if constexpr (IN_MODE == IN_ENC) nerf_load_encoded<NCT, SPLIT, false>(a, sidx, g, pe_h, pe_l, de_h, de_l);
 
     // ---- 2. start the weight stream: bias table, then the first 8 chunks
     WeightStream<C, SingleStreamMap<NFRAG>> ws;
@@ -47,7 +47,9 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES * C::WG_PER_CU / 4) 
     ws.prologue();
 
     // ---- 3. positional encoding into B fragments (overlaps the prefetch latency)
-    if constexpr (IN_MODE != IN_ENC) nerf_encode<NCT, SPLIT, FULL>(a, pos, dir, sidx, g, pe_h, pe_l, de_h, de_l);
+    // (points only: the direction is encoded in front of the colour head, nerf_encode_dir_late -- eight to sixteen
+    // registers that would otherwise sit idle through eleven layers)
+    if constexpr (IN_MODE != IN_ENC) nerf_encode<NCT, SPLIT, false>(a, pos, dir, sidx, g, pe_h, pe_l, de_h, de_l);
 
     const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * g);
     stamp(2);
@@ -115,6 +117,7 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES * C::WG_PER_CU / 4) 
             half8 Bh[9][NCT], Bl[9][NCT];
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
+                nerf_encode_dir_late<IN_MODE, SPLIT>(a, sidx[c], g, de_h[0][c], de_l[0][c]);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) Bh[k][c] = Yh[k][c], Bl[k][c] = Yl[k][c];
                 Bh[8][c] = de_h[0][c], Bl[8][c] = de_l[0][c];

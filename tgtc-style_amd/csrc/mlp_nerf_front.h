@@ -93,4 +93,20 @@ __device__ __forceinline__ void nerf_encode(const NerfArgs& a, const double (&po
     }
 }
 
+// Late direction encoding (kernels short of registers: the 27-wide direction encoding is only needed by the colour
+// head, eleven layers after the prologue): reload the direction of this lane's sample and encode it there.
+template <int IN_MODE, bool SPLIT>
+__device__ __forceinline__ void nerf_encode_dir_late(const NerfArgs& a, long long sidx, int g, half8& de_h, half8& de_l) {
+    const long long s = sidx < a.M ? sidx : a.M - 1;
+    if constexpr (IN_MODE == IN_ENC) {
+        load_encoded_dir<SPLIT>(a.dirs_enc + s * 27, g, de_h, de_l);
+    } else {
+        double d[3];
+        const double* src = IN_MODE == IN_RAYS ? a.rays_d + ((unsigned)s / (unsigned)a.N) * 3 : a.dirs + s * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k] = src[k];
+        encode_dir<SPLIT, SPLIT>(d, g, de_h, de_l, (a.out_dirs_enc && sidx < a.M) ? a.out_dirs_enc + sidx * 27 : nullptr);
+    }
+}
+
 }  // namespace tgtc

@@ -22,7 +22,10 @@ __global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
     constexpr int NQ = FULL ? kNerfMxTable.first[12] : kNerfMxTable.first[9];
     constexpr int NUNITS = mx_bytes_upto(kNerfMxTable, NQ) / 1024;
 
-    __shared__ __attribute__((aligned(16))) char smem[C::RING_BYTES + kNerfBiasBytes];
+    // ring | biases + row exponents | per-wave stash of the lo halves of the point encoding (needed again by the
+    // skip layer only; 8 registers per lane that would otherwise be spilled to scratch memory = HBM traffic)
+    constexpr int kStashBytes = C::NWAVES * 2048;
+    __shared__ __attribute__((aligned(16))) char smem[C::RING_BYTES + kNerfBiasBytes + kStashBytes];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -39,7 +42,7 @@ __global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
     long long sidx[1];
     nerf_load_samples<1, IN_MODE>(a, s_wave, n, pos, dir, sidx);
     half8 pe_h[2][1], pe_l[2][1], de_h[1][1], de_l[1][1];
-    if constexpr (IN_MODE == IN_ENC) nerf_load_encoded<1, true, FULL>(a, sidx, g, pe_h, pe_l, de_h, de_l);
+    if constexpr (IN_MODE == IN_ENC) nerf_load_encoded<1, true, false>(a, sidx, g, pe_h, pe_l, de_h, de_l);
 
     // ---- 2. bias / row-exponent table, then the first 8 chunks of the weight stream
     MxReader<C, SingleStreamMap<NUNITS>, kNerfMxTable> rd;
@@ -52,7 +55,8 @@ __global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
     rd.ring.prologue();
 
     // ---- 3. positional encoding (hi + lo fp16 B fragments)
-    if constexpr (IN_MODE != IN_ENC) nerf_encode<1, true, FULL>(a, pos, dir, sidx, g, pe_h, pe_l, de_h, de_l);
+    // (points only: the direction is encoded in front of the colour head, nerf_encode_dir_late)
+    if constexpr (IN_MODE != IN_ENC) nerf_encode<1, true, false>(a, pos, dir, sidx, g, pe_h, pe_l, de_h, de_l);
     const half8 Ph[2] = {pe_h[0][0], pe_h[1][0]}, Pl[2] = {pe_l[0][0], pe_l[1][0]};
 
     const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * g);
@@ -71,6 +75,8 @@ __global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
     constexpr const MxTable& T = kNerfMxTable;
 
     dense_mx<C, T.first[0], NQ, 16, 0, 2, L::bias0(0)>(rd, bias_lane, rs_lane, none, Ph, Pl, to_Y);
+    half8* const stash = reinterpret_cast<half8*>(smem + C::RING_BYTES + kNerfBiasBytes + wave * 2048) + lane;
+    stash[0] = Pl[0], stash[64] = Pl[1];
     stamp(4);
     dense_mx<C, T.first[1], NQ, 16, 2, 0, L::bias0(1)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
     stamp(5);
@@ -81,7 +87,10 @@ __global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
     dense_mx<C, T.first[4], NQ, 16, 2, 0, L::bias0(4)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
     stamp(8);
     // skip layer: reference input is cat(pe, h) (models.py:98-99); k order here is [h | pe]
-    dense_mx<C, T.first[5], NQ, 16, 2, 2, L::bias0(5)>(rd, bias_lane, rs_lane, Y, Ph, Pl, to_X);
+    {
+        const half8 Pl5[2] = {stash[0], stash[64]};
+        dense_mx<C, T.first[5], NQ, 16, 2, 2, L::bias0(5)>(rd, bias_lane, rs_lane, Y, Ph, Pl5, to_X);
+    }
     stamp(9);
     dense_mx<C, T.first[6], NQ, 16, 2, 0, L::bias0(6)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
     stamp(10);
@@ -106,6 +115,7 @@ __global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
             }
         });
         MxAct<1> Z;
+        nerf_encode_dir_late<IN_MODE, true>(a, sidx[0], g, de_h[0][0], de_l[0][0]);
         const half8 Dh[1] = {de_h[0][0]}, Dl[1] = {de_l[0][0]};
         dense_mx<C, T.first[10], NQ, 8, 2, 1, L::bias0(10)>(rd, bias_lane, rs_lane, Y, Dh, Dl, [&](auto rt_, auto h_, const float4v& acc) {
             mx_store_act<decltype(rt_)::value, decltype(h_)::value>(acc, Z, l16);
