@@ -54,10 +54,12 @@ def t_state(sd):
 
 
 def build_nets(precision):
+    """`precision` = one mode for both networks, or "coarse+fine" (precision belongs to each network handle)."""
     from tgtc_style_amd import models, synth
     nets = []
-    for seed, mode in ((0, "coarse"), (1, "fine")):
-        a = type("A", (NetArgs,), {"precision": precision})
+    per_net = precision.split("+") * 2
+    for (seed, mode), prec in zip(((0, "coarse"), (1, "fine")), per_net):
+        a = type("A", (NetArgs,), {"precision": prec})
         m = models.StyleNerf(a, mode=mode)
         m.load_state_dict(t_state(synth.nerf_state(seed)))
         m = m.cuda()
@@ -123,9 +125,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="fp16x3", choices=["fp16x3", "fp16", "fp16mx"])
+    ap.add_argument("--precision", default="fp16x3",
+                    help="fp16x3 | fp16mx | fp16, or coarse+fine, e.g. fp16x3+fp16mx")
     ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the CPU baseline sample (0 disables)")
-    ap.add_argument("--alt-precision", default="fp16mx,fp16",
+    ap.add_argument("--alt-precision", default="fp16x3+fp16mx,fp16mx,fp16",
                     help="further precisions (comma separated) reported under `alt_precisions` ('' disables)")
     ap.add_argument("--workload", default="plain", choices=["plain", "styled", "style2d"],
                     help="plain = BASELINE config 2 (the headline); styled = config 3's ray path (concat + style MLPs); "
@@ -160,11 +163,14 @@ def main():
                  "fp16mx": "fp16 product + two block-scaled fp6 correction products: rgb within 1e-3 of the reference's own "
                            "renders, composited depth 2e-3; block scaling makes the margin weight dependent, so the "
                            "element-wise fp16x3 split stays the headline parity mode",
-                 "fp16x3": "fp16 hi+lo split, three MFMA products: fp32-equivalent"}
+                 "fp16x3": "fp16 hi+lo split, three MFMA products: fp32-equivalent",
+                 "fp16x3+fp16mx": "coarse pass fp16x3, fine pass fp16mx: rgb 2.5e-4 and depth 2.1e-4 against the reference's own "
+                                  "renders (the inverse-CDF step amplifies coarse-pass errors only); block-scaling caveat of fp16mx "
+                                  "applies to the fine network"}
         for p, alt in zip(alts, alt_lines):
             entry = {k: alt[k] for k in ("value", "ms_per_step", "dtype")}
             entry.update(precision=p, roofline_frac=alt["roofline"]["frac"], kernel_ms=alt["roofline"]["kernel_ms"],
-                         mfma_pipe_frac=alt["roofline"]["mfma_pipe_frac"], note=notes[p])
+                         mfma_pipe_frac=alt["roofline"]["mfma_pipe_frac"], note=notes.get(p, ""))
             line.setdefault("alt_precisions", []).append(entry)
             if p == "fp16":
                 line["alt_precision"] = entry
@@ -251,7 +257,8 @@ def run_rays(args, precision, rank, world, dist):
         flop_launch = 2.0 * MAC_FULL * n_rays * (N_COARSE + N_FINE)      # algorithmic flop of one fine-pass launch
         achieved = flop_launch / (kernel_ms * 1e-3) / 1e12
         # MFMA issue slots per algorithmic product: fp16mx = 4 f16 + 2 fp6 16x16x128 instructions per 128-deep block
-        mfma_per_product = {"fp16x3": 3.0, "fp16": 1.0, "fp16mx": 1.5}[precision]
+        fine_prec = precision.split("+")[-1]          # the timed kernel is the fine pass
+        mfma_per_product = {"fp16x3": 3.0, "fp16": 1.0, "fp16mx": 1.5}[fine_prec]
         line = {
             "metric": "rays/sec (128c+64f samples) on fern 400x400",
             "value": rays_total / dt,
@@ -265,16 +272,17 @@ def run_rays(args, precision, rank, world, dist):
             "vs_baseline": None,
             "dtype": {"fp16x3": "f16 MFMA operands split hi+lo (3 products), f32 accumulate",
                       "fp16": "f16 MFMA operands, f32 accumulate",
-                      "fp16mx": "f16 MFMA product + two block-scaled fp6 (e2m3) correction products, f32 accumulate"}[precision],
+                      "fp16mx": "f16 MFMA product + two block-scaled fp6 (e2m3) correction products, f32 accumulate"}[fine_prec]
+                     + ("" if "+" not in precision else " (fine pass; coarse pass: %s)" % precision.split("+")[0]),
             "data": "synthetic",
             "config": {"workload": "fern-shaped 400x400 frame, plain NeRF render (style off), 128 coarse + 64 fine "
                                    "samples/ray, one whole frame per rank per step, seeded random-init weights",
                        "rays_per_step": world * n_rays, "precision": precision, "sharding": "frames",
                        "algorithmic_mflop_per_ray": FLOP_PER_RAY / 1e6},
-            "roofline": {"bound": "mfma", "kernel": ("nerf_mx_kernel<FULL>" if precision == "fp16mx" else "nerf_mlp_kernel<FULL>") + " (fine pass: PE + 12 dense layers, %d samples)"
+            "roofline": {"bound": "mfma", "kernel": ("nerf_mx_kernel<FULL>" if fine_prec == "fp16mx" else "nerf_mlp_kernel<FULL>") + " (fine pass: PE + 12 dense layers, %d samples)"
                                                    % (n_rays * (N_COARSE + N_FINE)),
                          "achieved": achieved, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP16_TFLOPS, "traffic": PMC_TRAFFIC_BYTES.get(precision),
+                         "frac": achieved / PEAK_FP16_TFLOPS, "traffic": PMC_TRAFFIC_BYTES.get(fine_prec),
                          "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/)",
                          "algorithmic_bytes_per_launch": n_rays * (N_COARSE + N_FINE) * 20,
                          "kernel_ms": kernel_ms, "algorithmic_tflop_per_launch": flop_launch / 1e12,
