@@ -127,3 +127,32 @@ def test_render_rays_styled_golden(golden, precision, nc, nf):
              for k, a, b in (("rgb", "rgb", "styled_rgb"), ("t", "t", "styled_t"), ("rgb_coarse", "rgb_coarse", "styled_rgb_coarse"))}
         print(precision, tag, jt, e)
         assert max(e.values()) <= lim, e
+
+
+def test_render_styled_full_size_properties():
+    """BASELINE size (128c+64f) on a 20-row strip of a 400-wide frame through the fused stylised chain: range,
+    finiteness, shard independence (a rank's sub-range reproduces the same bits), and a spot check of 128 rays against
+    the oracle."""
+    from oracle import fields
+    from tgtc_style_amd import models, rendering, utils
+    H, W = 400, 400
+    cm, sm, nets = make("fp16x3")
+    lat = models.StyleLatents_variational(style_num=1, frame_num=20, latent_dim=32)
+    lat.load_state_dict(T(synth.latents_state(4)))
+    lat = lat.cuda()
+    lat.sigma_scale = 1.0
+    ro, rd = utils.gen_rays(H, W, synth.fern_intrinsics(H, W), synth.spiral_pose(5), first_pixel=180 * W, n=20 * W)
+    R = ro.shape[0]
+    z = lat(style_ids=torch.zeros(R, dtype=torch.long), frame_ids=torch.full((R,), 7, dtype=torch.long), type="llff")
+    r = rendering.RayRenderer(nets[0], nets[1], models.StylePair(cm, sm))
+    a = r.render(ro, rd, 128, 64, z=z)
+    assert a["rgb"].shape == (R, 3) and bool(torch.isfinite(a["rgb"]).all()) and bool(torch.isfinite(a["t"]).all())
+    assert float(a["rgb"].min()) >= 0 and float(a["rgb"].max()) <= 1 + 1e-5
+    b = r.render(ro[3000:5000].contiguous(), rd[3000:5000].contiguous(), 128, 64, z=z[3000:5000].contiguous())
+    assert torch.equal(a["rgb"][3000:5000], b["rgb"]) and torch.equal(a["t"][3000:5000], b["t"])
+    idx = torch.arange(0, R, R // 128)[:128]
+    ref = fields.render_styled(T(synth.nerf_state(0)), T(synth.nerf_state(1)), T(synth.concat_state(2)), T(synth.style_state(3)),
+                               ro[idx].cpu(), rd[idx].cpu(), z[idx].cpu(), 128, 64)
+    e = float((a["rgb"][idx].cpu() - ref["rgb_fine"]).abs().max())
+    print("styled 128c+64f, 128 rays vs oracle: rgb", e)
+    assert e <= 1e-3

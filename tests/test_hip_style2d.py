@@ -117,3 +117,41 @@ def test_stytrans_test_branch(golden, nets):
     # a square frame takes the same (test-branch) path here; the reference would fall into its training branch
     sq = style2d.StyTrans(vgg, dec, pe, tr)(content[..., :40], style[..., :40])
     assert sq[0].shape == (1, 3, 40, 40) and sq[1].shape == (1, 512, 5, 5)
+
+
+def test_full_size_layers_vs_oracle(nets):
+    """BASELINE size (400x400 frame -> 50x50 = 2 500 tokens): one attention block, one encoder-s layer and one decoder
+    layer against the CPU oracle (seconds on the host); the goldens above only cover 6x8-token maps."""
+    from oracle import style2d as o2d
+    p, tr, *_ = nets
+    sd = T(synth.transformer_state(5))
+    rng = np.random.default_rng(50)
+    n = 2500
+    src = torch.from_numpy(rng.standard_normal((n, 512)).astype(np.float32))
+    mem = torch.from_numpy(rng.standard_normal((n, 512)).astype(np.float32))
+    h = tr.handle()
+    with torch.no_grad():
+        e_a = rel(h.mha("decoder.layers.2.multihead_attn.", src.cuda(), mem.cuda(), mem.cuda()),
+                  o2d.mha(sd, "decoder.layers.2.multihead_attn.", src, mem, mem))
+        e_s = rel(h.encoder_layer("encoder_s.layers.0.", src.cuda(), False), o2d.encoder_layer(sd, "encoder_s.layers.0.", src, False))
+        e_d = rel(h.decoder_layer("decoder.layers.0.", src.cuda(), mem.cuda(), src.cuda() * 0.5),
+                  o2d.decoder_layer(sd, "decoder.layers.0.", src, mem, src * 0.5))
+    print(p, "2500 tokens: mha", e_a, "enc_s", e_s, "dec", e_d)
+    assert max(e_a, e_s, e_d) <= TOL[p]
+
+
+def test_full_size_decoder_and_vgg_vs_oracle(nets):
+    """CNN decoder [1,512,50,50] -> 400x400 and the VGG prefix on a 400x400 image against the CPU oracle."""
+    from oracle import style2d as o2d
+    p, tr, pe, dec, vgg = nets
+    rng = np.random.default_rng(51)
+    x = torch.from_numpy(rng.standard_normal((1, 512, 50, 50)).astype(np.float32))
+    img = torch.from_numpy(rng.uniform(0, 1, (1, 3, 400, 400)).astype(np.float32))
+    with torch.no_grad():
+        e_dec = rel(dec(x.cuda()), o2d.cnn_decode(T(synth.decoder_state(7)), x))
+        ref = o2d.vgg_encode(T(synth.vgg_state(8)), img)
+        got = vgg.encode_with_intermediate(img.cuda())
+        e_vgg = max(rel(got[i], ref[i]) for i in range(4))
+        e_pe = rel(pe(img.cuda()), o2d.patch_embed(T(synth.embed_state(6)), img))
+    print(p, "400x400: decoder", e_dec, "vgg", e_vgg, "embed", e_pe)
+    assert max(e_dec, e_vgg, e_pe) <= TOL[p]
