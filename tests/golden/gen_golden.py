@@ -448,8 +448,53 @@ def g10_image():
          depth8=np.stack([arr for n, arr in written if n.startswith("depth")]))
 
 
+# ----------------------------------------------------------------------------- G11 LLFF poses
+def g11_llff_poses():
+    """load_llff.load_llff_data (load_llff.py:233-305) run for real on a synthetic scene directory: a seeded
+    poses_bounds.npy plus empty image files, with the inert imageio placeholder returning blank frames of the right
+    size.  Records the raw array and everything the loader derives from it (recentred poses, bounds, the 120-view
+    spiral, the hold-out index) and dataset.py:101-102's cps_valid."""
+    import imageio
+    import load_llff as ref_llff
+    rng = np.random.default_rng(11)
+    n, H0, W0, focal0, factor = 20, 96, 128, 110.0, 8
+    arr = np.zeros((n, 17))
+    for i in range(n):
+        # LLFF convention (before the axis fix-up of load_llff.py:239): columns [down, right, backwards], position, hwf
+        ang = rng.normal(0, 0.08, 3)
+        cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+        R = (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+             @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+        pose = np.concatenate([R, rng.normal(0, 0.6, (3, 1)), np.array([[H0], [W0], [focal0]])], 1)
+        arr[i, :15] = pose.reshape(-1)
+        arr[i, 15:] = [rng.uniform(1.6, 2.4), rng.uniform(14, 22)]
+    out = {"poses_arr": arr, "factor": np.int64(factor), "image_hw": np.array([H0 // factor, W0 // factor])}
+    blank = np.zeros((H0 // factor, W0 // factor, 3), np.uint8)
+    imageio.imread = lambda f: np.zeros((H0, W0, 3), np.uint8) if os.sep + "images" + os.sep in f else blank
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            np.save(os.path.join(tmp, "poses_bounds.npy"), arr)
+            for d in ("images", "images_%d" % factor):
+                os.makedirs(os.path.join(tmp, d))
+                for i in range(n):
+                    open(os.path.join(tmp, d, "%03d.png" % i), "wb").close()
+            for flat in (False,):   # path_zflat=True divides N_views into a float and np.linspace refuses it (load_llff.py:283)
+                images, poses, bds, render_poses, i_test = ref_llff.load_llff_data(tmp, factor, recenter=True, bd_factor=.75,
+                                                                                   spherify=False, path_zflat=flat)
+                tag = ""
+                cps_valid = np.concatenate([render_poses[:, :3, :4], np.zeros_like(render_poses[:, :1, :4])], axis=1)  # dataset.py:101
+                cps_valid[:, 3, 3] = 1.
+                out.update({"poses" + tag: poses, "bds" + tag: bds, "render_poses" + tag: render_poses,
+                            "i_test" + tag: np.int64(i_test), "cps_valid" + tag: cps_valid})
+            assert images.shape == (n, H0 // factor, W0 // factor, 3)
+    finally:
+        del imageio.imread
+    save("g11_llff_poses", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (g1_rays, g2_coarse, g3_embed, g4_nerf, g5_composite, g6_fine, g7_style, g8_end_to_end, g9_style2d, g10_image):
+    for fn in (g1_rays, g2_coarse, g3_embed, g4_nerf, g5_composite, g6_fine, g7_style, g8_end_to_end, g9_style2d, g10_image,
+               g11_llff_poses):
         if not only or fn.__name__.split("_")[0] in only:
             fn()

@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 from tgtc_style_amd import config as cfg
@@ -57,3 +59,20 @@ def test_no_gpu_calls_fail_loudly_or_are_pure():
         from tgtc_style_amd import utils
         with pytest.raises(RuntimeError):
             utils.alpha_composition(torch.zeros(2, 4, 3), torch.zeros(2, 4), torch.zeros(2, 4))
+
+
+def test_llff_poses_golden(golden):
+    """llff_poses (host numpy, like the reference) against the reference's own load_llff_data run on a synthetic scene
+    directory (g11): recentred poses, rescaled bounds, the 120-view spiral, hold-out index, cps_valid."""
+    from tgtc_style_amd import llff_poses
+    g = golden("g11_llff_poses")
+    out = llff_poses.scene_poses(g["poses_arr"], tuple(int(v) for v in g["image_hw"]), factor=int(g["factor"]))
+    assert out["i_test"] == int(g["i_test"])
+    for k in ("poses", "bds", "render_poses"):
+        assert out[k].dtype == np.float32 and out[k].shape == g[k].shape, k
+        assert np.abs(out[k] - g[k]).max() <= 2e-6 * max(1.0, float(np.abs(g[k]).max())), k
+    cps = llff_poses.valid_camera_poses(out["render_poses"])
+    assert cps.shape == (120, 4, 4) and np.abs(cps - g["cps_valid"]).max() <= 2e-6 * float(np.abs(g["cps_valid"]).max())
+    # the spiral is closed and looks at one focus point: consecutive views differ smoothly, first != last
+    d = np.linalg.norm(np.diff(out["render_poses"][:, :3, 3], axis=0), axis=1)
+    assert d.max() < 4 * np.median(d) and np.linalg.norm(out["render_poses"][0, :3, 3] - out["render_poses"][-1, :3, 3]) > 0

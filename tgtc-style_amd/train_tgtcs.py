@@ -45,6 +45,25 @@ class SyntheticScene:
                        'style_id': torch.full((n,), sid, dtype=torch.long), 'frame_id': torch.full((n,), fid, dtype=torch.long)}
 
 
+class LlffPoseScene(SyntheticScene):
+    """A real LLFF scene as far as rendering needs it: camera poses from `<datadir>/poses_bounds.npy`
+    (llff_poses.scene_poses = load_llff.load_llff_data without the images; dataset.py:69-102), rays generated on the
+    device.  Training views = the recentred poses, validation views = the 120-view spiral (`valid_frames` of it)."""
+
+    def __init__(self, datadir, factor, device="cuda", valid_frames=None, style_num=1):
+        from . import llff_poses
+        arr = np.load(os.path.join(datadir, 'poses_bounds.npy'))
+        h0, w0 = arr[0, :15].reshape(3, 5)[:2, 4]
+        sc = llff_poses.scene_poses(arr, (int(h0 // factor), int(w0 // factor)), factor=factor)
+        self.h, self.w, self.f = int(sc["hwf"][0]), int(sc["hwf"][1]), float(sc["hwf"][2])
+        self.hwf = [self.h, self.w, self.f]
+        self.near, self.far = 0., 1.                                  # NDC (dataset.py:379-380)
+        self.cps = llff_poses.valid_camera_poses(sc["poses"])
+        self.cps_valid = llff_poses.valid_camera_poses(sc["render_poses"])[:valid_frames]
+        self.frame_num, self.style_num = self.cps.shape[0], style_num
+        self.mode, self.device = 'train', device
+
+
 class _Loader:
     def __init__(self, dataset, batch_size):
         self.dataset, self.batch_size = dataset, batch_size
@@ -97,11 +116,16 @@ def train(args):
         concat_model.load_state_dict(_t(synth.concat_state(2)))
         style_model.load_state_dict(_t(synth.style_state(3)))
 
-    if not args.synthetic:
-        raise SystemExit("train_tgtcs: the LLFF dataset loader is not part of this build (SURVEY section 8f); "
-                         "run with --synthetic")
-    hw = args.synthetic_hw
-    dataset = SyntheticScene(hw, hw, frames=20, valid_frames=args.synthetic_frames, device=device)
+    if os.path.exists(os.path.join(args.datadir, 'poses_bounds.npy')):
+        # rendering needs the cameras of the scene, not its images
+        dataset = LlffPoseScene(args.datadir, args.factor, device=device,
+                                valid_frames=args.synthetic_frames if args.synthetic else None)
+    elif args.synthetic:
+        hw = args.synthetic_hw
+        dataset = SyntheticScene(hw, hw, frames=20, valid_frames=args.synthetic_frames, device=device)
+    else:
+        raise SystemExit("train_tgtcs: no poses_bounds.npy in --datadir %s (the image side of the LLFF loader is not part "
+                         "of this build, SURVEY section 8f); run with --synthetic for the seeded scene" % args.datadir)
     latents = models.StyleLatents_variational(style_num=dataset.style_num, frame_num=dataset.frame_num,
                                               latent_dim=args.vae_latent).to(device)
     ck = None if args.no_reload else _newest(sv_path, ['tar', 'latent'], ['style'])       # train_tgtcs.py:139-146
