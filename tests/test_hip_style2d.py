@@ -1,6 +1,8 @@
 """GPU parity of the 2-D style pass (patch embed, transformer, CNN decoder, VGG, mean/std, AdaIN, post-processing)
 against the reference goldens (g9), through the C ABI.  Tolerance: 1e-3 max-norm relative (north-star) for the
 split-fp16 mode, which in practice sits at 1e-5..1e-4 after the 9-layer transformer; single fp16 is held to 3e-2."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -155,3 +157,24 @@ def test_full_size_decoder_and_vgg_vs_oracle(nets):
         e_pe = rel(pe(img.cuda()), o2d.patch_embed(T(synth.embed_state(6)), img))
     print(p, "400x400: decoder", e_dec, "vgg", e_vgg, "embed", e_pe)
     assert max(e_dec, e_vgg, e_pe) <= TOL[p]
+
+
+def test_stylize_frames_writes_reference_layout(tmp_path, nets):
+    """The per-style frame loop (trans_test.py:151-179): image files 001.., and `stylized_data.npz` with the reference's
+    keys; style_features is the plain mean of the per-frame [mean, unbiased var] rows (the zero row + /(n-1) of :145,178)."""
+    from PIL import Image
+    from tgtc_style_amd import style2d
+    p, tr, pe, dec, vgg = nets
+    net = style2d.StyTrans(vgg, dec, pe, tr)
+    rng = np.random.default_rng(60)
+    frames = [torch.from_numpy(rng.uniform(0, 1, (1, 3, 40, 56)).astype(np.float32)).cuda() for _ in range(3)]
+    style = torch.from_numpy(rng.uniform(0, 1, (1, 3, 40, 56)).astype(np.float32)).cuda()
+    imgs, feats = style2d.stylize_frames(net, frames, style, str(tmp_path), style_name="starry", style_path="/x/starry.jpg")
+    assert sorted(os.listdir(tmp_path)) == ["001.png", "002.png", "003.png", "stylized_data.npz"]
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "002.png")), imgs[1]) and imgs[1].shape == (40, 56, 3)
+    z = np.load(tmp_path / "stylized_data.npz", allow_pickle=True)
+    assert z["style_names"].item() == {"starry": 0} and str(z["style_paths"]) == "/x/starry.jpg"
+    assert z["style_images"].shape == (1, 40, 56, 3) and z["style_features"].shape == (1, 1024)
+    rows = [style2d.stylize_frame(net, f, style)[1].cpu().numpy().reshape(1024) for f in frames]
+    assert np.allclose(z["style_features"][0], np.mean(rows, 0), rtol=1e-5, atol=1e-6)
+    assert np.array_equal(feats, z["style_features"])

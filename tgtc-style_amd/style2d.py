@@ -7,6 +7,7 @@ Transformer; function.py:4-12 calc_mean_std; Style_function.py:15-24 adaptive_in
 reference checkpoints load with `load_state_dict`; forward runs the HIP kernels (eval mode, batch of 1).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -398,3 +399,32 @@ def stylize_frame(net, content, style):
     ics, hs = net(content, style)
     image = resize_bilinear(ics, content.shape[-2:])
     return image, style_feature(nchw_to_tokens(hs)), hs
+
+
+def stylize_frames(net, contents, style, output_path=None, style_name="style", style_path="", style_image=None, save_ext=".png"):
+    """The frame loop of trans_test.transformer_render (trans_test.py:151-179) for one style image.
+
+    contents: iterable of [1,3,h,w] CUDA tensors in [0,1]; style: [1,3,h,w].  Per frame: network, bilinear resize to the
+    content size (align_corners=True, :172-173), image file `NNN<ext>` counted from 001 (:168-170; torchvision.save_image
+    = x*255+0.5 clamped to uint8), and one row [mean_tokens(hs), var_tokens(hs)] (:176).  The rows are averaged exactly as
+    the reference does -- a zero row is prepended and the sum divided by rows-1 (:145,178) -- and written with the style
+    image to `stylized_data.npz` under the reference's keys (:179), which is what its dataset reads back
+    (dataset.py:437-440).  Returns (list of uint8 HWC images, style_features [1,1024] float32)."""
+    rows = np.zeros([1, 1024], dtype=np.float32)
+    images = []
+    for cnt, content in enumerate(contents, start=1):
+        image, feat, _ = stylize_frame(net, content, style)
+        rows = np.append(rows, [feat.detach().float().cpu().numpy().reshape(1024)], axis=0)
+        img8 = image[0].detach().mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).cpu().numpy()
+        images.append(img8)
+        if output_path is not None:
+            from PIL import Image
+            os.makedirs(output_path, exist_ok=True)
+            Image.fromarray(img8).save('{:s}/{:03d}{:s}'.format(output_path, cnt, save_ext))
+    features = np.sum(rows, axis=0, keepdims=True) / (rows.shape[0] - 1)
+    if output_path is not None:
+        if style_image is None:
+            style_image = np.moveaxis(style.detach().float().cpu().numpy(), 1, -1)          # [1,h,w,3] like :144
+        np.savez(os.path.join(output_path, 'stylized_data'), style_names={style_name: 0}, style_paths=style_path,
+                 style_images=style_image, style_features=features)
+    return images, features
