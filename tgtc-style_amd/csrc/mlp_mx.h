@@ -151,12 +151,23 @@ struct MxReader {
         refill_from<Q0, NQ, 0>();
         __builtin_amdgcn_sched_barrier(0);
     }
-    // entering group Q: acquire the chunks group Q+1 touches
+    // Entering group Q: acquire the chunks group Q+1 touches.  A boundary re-fills the slot of chunk c-1, and group Q
+    // itself may straddle chunks c-1 | c with its reads still in flight (they were issued while group Q-1 ran), so
+    // those reads are retired first: the empty asm "uses" make hipcc place its counted wait for them in front of the
+    // barrier (volatile asm statements and the barrier keep their order).  With groups of at most half a chunk the
+    // case cannot arise (group Q+1 would have to cover a whole chunk), so today this compiles to nothing; it guards
+    // the invariant should the group or chunk size change.
     template <int Q, int NQ>
     __device__ __forceinline__ void acquire() {
         if constexpr (Q + 1 < NQ) {
             constexpr int c0 = chunk_hi(Q) > 1 ? chunk_hi(Q) : 1, c1 = chunk_hi(Q + 1) - 1;
-            static_for<(c1 >= c0 ? c1 - c0 + 1 : 0)>([&](auto i) { ring.template boundary<c0 + decltype(i)::value>(); });
+            if constexpr (c1 >= c0) {
+                if constexpr (T.off[Q] / kChunkBytes < c0) {
+                    static_for<(units(Q) < 4 ? units(Q) : 4)>([&](auto j) { asm volatile("" ::"v"(u[decltype(j)::value])); });
+                    if constexpr (units(Q) == 8) asm volatile("" ::"v"(w6[0]), "v"(w6[1]));
+                }
+                static_for<c1 - c0 + 1>([&](auto i) { ring.template boundary<c0 + decltype(i)::value>(); });
+            }
         }
     }
 };
