@@ -230,10 +230,6 @@ struct WeightStream {
     // instructions -- what fits into the ~8 spare issue cycles of a 16x16x32 MFMA -- then fence the window.
     template <int F, int N_MFMA, int EXTRA_READS>
     __device__ __forceinline__ void close_window() const {
-#ifdef TGTC_ASM_MFMA
-        __builtin_amdgcn_sched_barrier(0);
-        return;
-#endif
         constexpr int NR = reads_in_window(F) + EXTRA_READS;
         static_for<N_MFMA>([&](auto i_) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
@@ -255,36 +251,6 @@ struct WeightStream {
 
 __device__ __forceinline__ float4v mfma16(half8 a, half8 b, float4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-
-// Register-class-pinned MFMA.  hipcc parks the fp32 accumulators in the AGPR half of the register file, so
-// every ReLU/convert epilogue pays one v_accvgpr_read per value (16 per row tile) on an issue port that a
-// 16x16x32 MFMA leaves only ~8 free cycles on.  Pinning the accumulator to arch VGPRs ("+v") and the
-// activation fragments -- which only MFMAs ever read -- to the accumulator file ("a") removes those moves.
-// Inline asm is opaque to the hazard recogniser: `s_nop 1` covers VALU / v_accvgpr_write -> MFMA operand
-// (2 wait states); MFMA result -> VALU readers are separated by >= 3 MFMAs by construction (deferred
-// epilogue) or by mfma_drain() before a layer's flush.
-template <bool B_IN_AGPR>
-__device__ __forceinline__ void mfma16_pinned(float4v& acc, half8 a, half8 b) {
-#ifndef TGTC_ASM_NOP
-#define TGTC_ASM_NOP "s_nop 1\n\t"
-#endif
-#ifdef TGTC_ASM_B_VGPR_ONLY
-    asm volatile(TGTC_ASM_NOP "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-#else
-    if constexpr (B_IN_AGPR)
-        asm volatile(TGTC_ASM_NOP "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
-    else
-        asm volatile(TGTC_ASM_NOP "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-#endif
-}
-// Wait out the matrix pipe before VALU code reads accumulators written by the pinned (asm) MFMAs.  The
-// accumulators are named as operands: a "memory" clobber does not order register-only instructions.
-template <int N>
-__device__ __forceinline__ void mfma_drain(float4v (&acc)[N]) {
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]));
-#pragma unroll
-    for (int c = 1; c < N; ++c) asm volatile("" : "+v"(acc[c]));
 }
 
 // One dense layer.  B operands: Bh[KS][NCT] (+ Bl in split mode).  Fragment (rt,ks) is stream
@@ -314,18 +280,6 @@ __device__ __forceinline__ void dense_layer(StreamT& st, lds_cptr bias_lane, con
             half8 ah, al;
             st.template get<FRAG0 + rt * KS + ks>(ah, al);
             if constexpr (ks == 0 && rt + 1 < RT) bias[cur ^ 1] = *(lds_f4)(bias_lane + (BIAS0 + 16 * (rt + 1)) * 4);
-#ifdef TGTC_ASM_MFMA
-            // k-steps below KSA carry activations of a previous layer (accumulator file), the rest encodings / latents
-            constexpr int KSA = KS >= 16 ? 16 : (KS >= 8 ? 8 : (KS == 4 ? 4 : 0));
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) mfma16_pinned<(ks < KSA)>(acc[cur][c], ah, Bh[ks][c]);
-            if constexpr (C::SPLIT) {
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) mfma16_pinned<(ks < KSA)>(acc[cur][c], al, Bh[ks][c]);
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) mfma16_pinned<(ks < KSA)>(acc[cur][c], ah, Bl[ks][c]);
-            }
-#else
 #pragma unroll
             for (int c = 0; c < NCT; ++c) acc[cur][c] = mfma16(ah, Bh[ks][c], acc[cur][c]);
             if constexpr (C::SPLIT) {
@@ -334,7 +288,6 @@ __device__ __forceinline__ void dense_layer(StreamT& st, lds_cptr bias_lane, con
 #pragma unroll
                 for (int c = 0; c < NCT; ++c) acc[cur][c] = mfma16(ah, Bl[ks][c], acc[cur][c]);
             }
-#endif
             if constexpr (rt > 0) {
                 static_for<PER>([&](auto p_) {
                     constexpr int u = ks * PER + decltype(p_)::value;
@@ -344,9 +297,6 @@ __device__ __forceinline__ void dense_layer(StreamT& st, lds_cptr bias_lane, con
             st.template close_window<FRAG0 + rt * KS + ks, NCT * (C::SPLIT ? 3 : 1), (ks == 0 && rt + 1 < RT) ? 1 : 0>();
         });
     });
-#ifdef TGTC_ASM_MFMA
-    mfma_drain(acc[(RT - 1) & 1]);
-#endif
     static_for<UNITS>([&](auto u_) {
         constexpr int u = decltype(u_)::value;
         epi(ic<RT - 1>{}, ic<u / 2>{}, ic<u % 2>{}, acc[(RT - 1) & 1][u / 2]);
