@@ -1,0 +1,122 @@
+// Does LDS -> VGPR return traffic slow the matrix pipe down?  8 waves per CU (2 per SIMD), each iteration issues
+// NMF independent 16x16x32 f16 MFMAs and NRD ds_read_b128 (1 KiB per wave-instruction) whose data feed the NEXT
+// iteration's MFMAs (double buffered, counted lgkmcnt waits since no LDS-DMA is visible to the compiler).
+// Prints s_memtime cycles per iteration per wave; compare against NMF*16*2 (two waves share a SIMD's pipe) and
+// NRD*8 waves*1 KiB / 256 B per clk.
+// hipcc --offload-arch=gfx950 -O3 -o lds_mfma_mix lds_mfma_mix.hip && ./lds_mfma_mix
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const char* lds_cptr;
+typedef __attribute__((address_space(3))) const half8* lds_h8;
+
+template <int NMF, int NRD, int NCH, int BAR, int NVALU, int IVALU = 0, int EVERY = 1>
+__global__ void __launch_bounds__(512, 2) k(unsigned long long* out, float* sink, int iters) {
+    __shared__ __attribute__((aligned(16))) char smem[131072];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 131072 / 4; i += blockDim.x) ((float*)smem)[i] = 0.001f * (i & 1023);
+    __syncthreads();
+    unsigned a0 = (unsigned)(size_t)((lds_cptr)smem + lane * 16);
+    asm volatile("" : "+v"(a0));
+    lds_cptr base = (lds_cptr)(size_t)a0;
+    float4v acc[8];
+    for (int c = 0; c < 8; ++c) acc[c] = float4v{0, 0, 0, 0};
+    half8 b[4];
+    for (int c = 0; c < 4; ++c)
+        for (int j = 0; j < 8; ++j) b[c][j] = (_Float16)(0.01f * (lane + j + c));
+    constexpr int NQ = NRD > 0 ? NRD : 1;
+    half8 q[2][NQ];
+    for (int j = 0; j < NQ; ++j) q[0][j] = q[1][j] = b[j & 3];
+    float junk = 0.001f * lane;
+    float jv[8];
+    for (int v = 0; v < 8; ++v) jv[v] = 0.1f * v + lane;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int m = 0; m < NMF; ++m) {
+                const half8 a = NRD > 0 ? q[half][m % NQ] : b[(m + 1) & 3];
+                acc[m % NCH] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[m & 3], acc[m % NCH], 0, 0, 0);
+                if (NRD > 0 && m < NRD)   // one read behind each of the first NRD MFMAs, into the other buffer
+                    q[half ^ 1][m] = *(lds_h8)(base + ((it + half) & 7) * 8192 + m * 1024);
+                if (IVALU > 0 && m % EVERY == EVERY - 1) {   // IVALU independent VALU instructions behind every EVERY-th MFMA
+#pragma unroll
+                    for (int v = 0; v < IVALU; ++v) jv[(m * IVALU + v) & 7] = jv[(m * IVALU + v) & 7] * 1.0001f + 0.5f;
+                }
+            }
+            if (NVALU > 0) {   // epilogue-like VALU work (max, cvt, sub) on values the MFMAs do not depend on
+#pragma unroll
+                for (int v = 0; v < NVALU; ++v) junk = fmaxf(junk * 1.0001f, (float)(_Float16)junk) - 0.5f;
+            }
+            if (BAR) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = junk;
+    for (int v = 0; v < 8; ++v) s += jv[v];
+    for (int c = 0; c < 8; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+    sink[blockIdx.x * 512 + threadIdx.x] = s;
+    if (lane == 0) out[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int NMF, int NRD, int NCH = 8, int BAR = 0, int NVALU = 0, int IVALU = 0, int EVERY = 1>
+static void run(unsigned long long* dout, float* dsink) {
+    const int iters = 4000, blocks = 256;
+    hipLaunchKernelGGL((k<NMF, NRD, NCH, BAR, NVALU, IVALU, EVERY>), dim3(blocks), dim3(512), 0, 0, dout, dsink, iters);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(blocks * 8);
+    hipMemcpy(h.data(), dout, h.size() * 8, hipMemcpyDeviceToHost);
+    double sum = 0;
+    for (auto v : h) sum += (double)v;
+    const double cyc = sum / h.size() / iters;
+    printf("NMF %2d NRD %d chains %d barrier %d bulk-valu %2d valu %d behind every %d. mfma : %7.1f cycles / iteration / wave   (MFMA pipe %4d, LDS array %4d)  pipe busy %.2f\n", NMF, NRD, NCH, BAR, NVALU, IVALU, EVERY, cyc,
+           NMF * 16 * 2, NRD * 8 * 4, NMF * 32.0 / cyc, NMF * 25.6 / cyc);
+}
+
+int main() {
+    unsigned long long* dout;
+    float* dsink;
+    hipMalloc(&dout, 256 * 8 * 8);
+    hipMalloc(&dsink, 256 * 512 * 4);
+    run<8, 0>(dout, dsink);
+    run<8, 2>(dout, dsink);
+    run<8, 4>(dout, dsink);
+    run<8, 6>(dout, dsink);
+    run<8, 8>(dout, dsink);
+    run<6, 7>(dout, dsink);   // fp16mx-like ratio (7 KiB per 6 MFMAs)
+    run<12, 8>(dout, dsink);  // fp16x3-like ratio (8 KiB per 12 MFMAs)
+    run<16, 4>(dout, dsink);  // fp16 NCT=2-like ratio (4 KiB per 16 MFMAs... per wave 8 MFMA-pairs)
+    printf("dependent accumulator chains, as in the kernels:\n");
+    run<12, 0, 1>(dout, dsink);
+    run<12, 8, 1>(dout, dsink);  // fp16x3: one chain
+    run<12, 8, 2>(dout, dsink);
+    run<16, 0, 2>(dout, dsink);
+    run<16, 4, 2>(dout, dsink);  // fp16 NCT=2: two chains
+    run<6, 7, 2>(dout, dsink);   // fp16mx: two chains
+    printf("plus a workgroup barrier per iteration / plus epilogue-like VALU work:\n");
+    run<12, 8, 1, 1, 0>(dout, dsink);
+    run<12, 8, 1, 0, 12>(dout, dsink);
+    run<12, 8, 1, 0, 24>(dout, dsink);
+    run<12, 8, 1, 1, 12>(dout, dsink);
+    run<16, 4, 2, 1, 0>(dout, dsink);
+    run<16, 4, 2, 0, 16>(dout, dsink);
+    run<16, 4, 2, 1, 16>(dout, dsink);
+    printf("independent VALU instructions interleaved behind every MFMA:\n");
+    run<12, 8, 1, 0, 0, 1>(dout, dsink);
+    run<12, 8, 1, 0, 0, 2>(dout, dsink);
+    run<12, 8, 1, 0, 0, 3>(dout, dsink);
+    run<12, 0, 1, 0, 0, 2>(dout, dsink);
+    run<16, 4, 2, 0, 0, 1>(dout, dsink);
+    run<16, 4, 2, 0, 0, 2>(dout, dsink);
+    printf("the same VALU count, clustered:\n");
+    run<12, 8, 1, 0, 0, 3, 3>(dout, dsink);
+    run<12, 8, 1, 0, 0, 6, 6>(dout, dsink);
+    run<12, 8, 1, 0, 0, 12, 12>(dout, dsink);
+    run<16, 4, 2, 0, 0, 4, 4>(dout, dsink);
+    run<16, 4, 2, 0, 0, 8, 8>(dout, dsink);
+    return 0;
+}
