@@ -2,7 +2,7 @@
 """Correctness probe for development libraries (TGTC_LIB=...): fp16 ray-mode NeRF kernels vs the oracle."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from oracle import fields
 from tgtc_style_amd import hip, synth

@@ -2,7 +2,7 @@
 """Development probe: where does the fp16 fine pass differ from fp16x3 on a full-frame ray sample?"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from oracle import fields
 from tgtc_style_amd import hip, synth, utils, rendering, models

@@ -2,7 +2,7 @@
 """Development probe: fp16mx NeRF kernels (all input modes) vs the oracle, with NaN maps."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from oracle import fields
 from tgtc_style_amd import hip, synth

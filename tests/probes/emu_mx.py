@@ -2,7 +2,7 @@
 """CPU emulation of the fp16+fp6 arithmetic (mlp_mx.h) on the synthetic NeRF: what error does the scheme itself leave?"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import fields
 from tgtc_style_amd import synth
 

@@ -3,7 +3,7 @@
 the oracle on 1024 rays of a fern-shaped frame and against the reference's own renders (golden g8)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from oracle import fields
 from tgtc_style_amd import hip, synth, utils, rendering, models
@@ -19,7 +19,7 @@ ro, rd = utils.gen_rays(H, W, synth.fern_intrinsics(H, W), synth.spiral_pose(3))
 idx = torch.arange(0, H * W, H * W // 1024)[:1024].cuda()
 ro, rd = ro[idx].contiguous(), rd[idx].contiguous()
 ref = fields.render_plain(t(synth.nerf_state(0)), t(synth.nerf_state(1)), ro.cpu(), rd.cpu(), 128, 64)
-g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "g8_end_to_end.npz"))
+g = np.load(os.path.join(os.path.dirname(__file__), "..", "golden", "g8_end_to_end.npz"))
 gro, grd = torch.from_numpy(g["rays_o_128c64f"]).cuda(), torch.from_numpy(g["rays_d_128c64f"]).cuda()
 for pc in ("fp16x3", "fp16mx", "fp16"):
     for pf in ("fp16x3", "fp16mx", "fp16"):
