@@ -1,0 +1,64 @@
+"""GPU: the N>1 path with the real kernels -- two ranks (gloo rendezvous on 127.0.0.1, both on the one GPU of the test
+box) render disjoint pixel ranges of a frame through the C ABI and gather them; the result must be bit-identical to the
+single-rank render (rays are independent, every kernel's per-ray arithmetic is position independent)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_path, n_pixels, H, W):
+    import torch.distributed as dist
+    from tgtc_style_amd import models, parallel, rendering, synth, utils
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+
+    class A:
+        use_viewdir, act_type = True, "relu"
+        embed_freq_coor, embed_freq_dir = 10, 4
+        netdepth = netdepth_fine = 8
+        netwidth = netwidth_fine = 256
+        precision = "fp16x3"
+
+    nets = []
+    for seed, mode in ((0, "coarse"), (1, "fine")):
+        m = models.StyleNerf(A, mode=mode)
+        m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.nerf_state(seed).items()})
+        nets.append(m.cuda())
+    r = rendering.RayRenderer(*nets)
+    focal, pose = synth.fern_intrinsics(H, W), synth.spiral_pose(4)
+
+    def make_rays(first, n):
+        return utils.gen_rays(H, W, focal, pose, first_pixel=first, n=n)
+
+    def render(o, d):
+        out = r.render(o, d, 128, 64)
+        return out["rgb"].cpu(), out["t"].cpu()          # gloo gathers host tensors; RCCL would take them on the device
+
+    frame = parallel.render_frame_sharded(render, make_rays, n_pixels, rank, world, dist)
+    if rank == 0:
+        rgb, t = render(*make_rays(0, n_pixels))
+        whole = torch.cat([rgb, t[:, None]], 1)
+        np.save(out_path, np.array([int(torch.equal(frame, whole)), frame.shape[0], int(torch.isfinite(frame).all())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pixels", [40 * 400, 4001])      # an even split and a ragged one
+def test_two_ranks_equal_one(tmp_path, n_pixels):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.npy")
+    mp.spawn(_worker, args=(2, _free_port(), out, n_pixels, 400, 400), nprocs=2, join=True)
+    same, rows, finite = np.load(out)
+    assert rows == n_pixels and finite == 1 and same == 1
