@@ -225,13 +225,14 @@ def test_render_adversarial_scene():
     assert rel(per["sigma"], ref_c["sigma"]) <= 5e-5 and rel(per["rgb"], ref_c["rgb"]) <= 5e-5
 
 
-def test_render_full_size_properties():
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16mx", "fp16"])
+def test_render_full_size_properties(precision):
     """BASELINE size (128c+64f) on a whole 400-wide strip: properties that do not need the oracle."""
     from tgtc_style_amd import rendering, utils
     H, W = 400, 400
     focal = synth.fern_intrinsics(H, W)
     ro, rd = utils.gen_rays(H, W, focal, synth.spiral_pose(3), first_pixel=0, n=40 * W)
-    r = rendering.RayRenderer(make_nerf(0, "coarse", "fp16x3"), make_nerf(1, "fine", "fp16x3"))
+    r = rendering.RayRenderer(make_nerf(0, "coarse", precision), make_nerf(1, "fine", precision))
     a = r.render(ro, rd, 128, 64)
     assert a["rgb"].shape == (40 * W, 3) and bool(torch.isfinite(a["rgb"]).all())
     assert float(a["rgb"].min()) >= 0 and float(a["rgb"].max()) <= 1 + 1e-5       # convex combination of sigmoids
@@ -239,6 +240,8 @@ def test_render_full_size_properties():
     # rays are independent: any sub-range (a rank's shard, any chunking) reproduces the same bits
     b = r.render(ro[5000:9000].contiguous(), rd[5000:9000].contiguous(), 128, 64)
     assert torch.equal(a["rgb"][5000:9000], b["rgb"]) and torch.equal(a["t"][5000:9000], b["t"])
+    if precision != "fp16x3":
+        return
     # spot check 256 of the rays against the oracle
     idx = torch.arange(0, 40 * W, 40 * W // 256)[:256]
     ref = fields.render_plain(T(synth.nerf_state(0)), T(synth.nerf_state(1)), ro[idx].cpu(), rd[idx].cpu(), 128, 64)
