@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase cycle shares of the fused NeRF kernel from in-kernel s_memtime stamps.
-Run on the GPU box: python tools/stamp_profile.py [fp16|fp16x3]"""
+Run on the GPU box: python tools/stamp_profile.py [fp16|fp16x3|fp16mx] [waves] [column tiles]
+
+The "ideal MFMA" column prices a 16x16x32 MFMA at 16 cycles (the 2.4 GHz peak); in s_memtime units the pipe actually
+turns one around in 12.6 (tools/microbench/lds_mfma_mix), so eff x 2 waves x 0.79 is the share of the matrix pipe."""
 import os
 import sys
 
