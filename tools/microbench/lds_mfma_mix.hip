@@ -12,7 +12,7 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const char* lds_cptr;
 typedef __attribute__((address_space(3))) const half8* lds_h8;
 
-template <int NMF, int NRD, int NCH, int BAR, int NVALU, int IVALU = 0, int EVERY = 1>
+template <int NMF, int NRD, int NCH, int BAR, int NVALU, int IVALU = 0, int EVERY = 1, int KIND = 0>
 __global__ void __launch_bounds__(512, 2) k(unsigned long long* out, float* sink, int iters) {
     __shared__ __attribute__((aligned(16))) char smem[131072];
     const int lane = threadIdx.x & 63;
@@ -44,7 +44,14 @@ __global__ void __launch_bounds__(512, 2) k(unsigned long long* out, float* sink
                     q[half ^ 1][m] = *(lds_h8)(base + ((it + half) & 7) * 8192 + m * 1024);
                 if (IVALU > 0 && m % EVERY == EVERY - 1) {   // IVALU independent VALU instructions behind every EVERY-th MFMA
 #pragma unroll
-                    for (int v = 0; v < IVALU; ++v) jv[(m * IVALU + v) & 7] = jv[(m * IVALU + v) & 7] * 1.0001f + 0.5f;
+                    for (int v = 0; v < IVALU; ++v) {
+                        float& x = jv[(m * IVALU + v) & 7];
+                        if (KIND == 0) x = x * 1.0001f + 0.5f;                                              // v_fma_f32
+                        else if (KIND == 1) x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), it));   // v_max_i32
+                        else if (KIND == 2) x = (float)(_Float16)x;                                          // v_cvt_f16_f32 + v_cvt_f32_f16
+                        else if (KIND == 3) x = x - jv[(m + 1) & 7];                                         // v_sub_f32
+                        else if (KIND == 4) asm volatile("v_mov_b32 %0, %0" : "+v"(x));                      // v_mov_b32
+                    }
                 }
             }
             if (NVALU > 0) {   // epilogue-like VALU work (max, cvt, sub) on values the MFMAs do not depend on
@@ -63,17 +70,17 @@ __global__ void __launch_bounds__(512, 2) k(unsigned long long* out, float* sink
     if (lane == 0) out[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
-template <int NMF, int NRD, int NCH = 8, int BAR = 0, int NVALU = 0, int IVALU = 0, int EVERY = 1>
+template <int NMF, int NRD, int NCH = 8, int BAR = 0, int NVALU = 0, int IVALU = 0, int EVERY = 1, int KIND = 0>
 static void run(unsigned long long* dout, float* dsink) {
     const int iters = 4000, blocks = 256;
-    hipLaunchKernelGGL((k<NMF, NRD, NCH, BAR, NVALU, IVALU, EVERY>), dim3(blocks), dim3(512), 0, 0, dout, dsink, iters);
+    hipLaunchKernelGGL((k<NMF, NRD, NCH, BAR, NVALU, IVALU, EVERY, KIND>), dim3(blocks), dim3(512), 0, 0, dout, dsink, iters);
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(blocks * 8);
     hipMemcpy(h.data(), dout, h.size() * 8, hipMemcpyDeviceToHost);
     double sum = 0;
     for (auto v : h) sum += (double)v;
     const double cyc = sum / h.size() / iters;
-    printf("NMF %2d NRD %d chains %d barrier %d bulk-valu %2d valu %d behind every %d. mfma : %7.1f cycles / iteration / wave   (MFMA pipe %4d, LDS array %4d)  pipe busy %.2f\n", NMF, NRD, NCH, BAR, NVALU, IVALU, EVERY, cyc,
+    printf("NMF %2d NRD %d chains %d barrier %d bulk-valu %2d valu %d behind every %d. mfma kind %d : %7.1f cycles / iteration / wave   (MFMA pipe %4d, LDS array %4d)  pipe busy %.2f\n", NMF, NRD, NCH, BAR, NVALU, IVALU, EVERY, KIND, cyc,
            NMF * 16 * 2, NRD * 8 * 4, NMF * 32.0 / cyc, NMF * 25.6 / cyc);
 }
 
@@ -112,6 +119,12 @@ int main() {
     run<12, 0, 1, 0, 0, 2>(dout, dsink);
     run<16, 4, 2, 0, 0, 1>(dout, dsink);
     run<16, 4, 2, 0, 0, 2>(dout, dsink);
+    printf("one VALU instruction of each kind behind every MFMA (0 fma, 1 max_i32, 2 cvt f16 round trip = 2 instr, 3 sub, 4 mov), no LDS reads:\n");
+    run<12, 0, 1, 0, 0, 1, 1, 0>(dout, dsink);
+    run<12, 0, 1, 0, 0, 1, 1, 1>(dout, dsink);
+    run<12, 0, 1, 0, 0, 1, 1, 2>(dout, dsink);
+    run<12, 0, 1, 0, 0, 1, 1, 3>(dout, dsink);
+    run<12, 0, 1, 0, 0, 1, 1, 4>(dout, dsink);
     printf("the same VALU count, clustered:\n");
     run<12, 8, 1, 0, 0, 3, 3>(dout, dsink);
     run<12, 8, 1, 0, 0, 6, 6>(dout, dsink);
