@@ -6,14 +6,15 @@
 // hipcc --offload-arch=gfx950 -O3 -o lds_mfma_mix lds_mfma_mix.hip && ./lds_mfma_mix
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <type_traits>
 #include <vector>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const char* lds_cptr;
 typedef __attribute__((address_space(3))) const half8* lds_h8;
 
-template <int NMF, int NRD, int NCH, int BAR, int NVALU, int IVALU = 0, int EVERY = 1, int KIND = 0>
-__global__ void __launch_bounds__(512, 2) k(unsigned long long* out, float* sink, int iters) {
+template <int NMF, int NRD, int NCH, int BAR, int NVALU, int IVALU = 0, int EVERY = 1, int KIND = 0, int RING = 0>
+__global__ void __launch_bounds__(512, 2) k(unsigned long long* out, float* sink, int iters, const char* wsrc) {
     __shared__ __attribute__((aligned(16))) char smem[131072];
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 131072 / 4; i += blockDim.x) ((float*)smem)[i] = 0.001f * (i & 1023);
@@ -33,6 +34,8 @@ __global__ void __launch_bounds__(512, 2) k(unsigned long long* out, float* sink
     float jv[8];
     for (int v = 0; v < 8; ++v) jv[v] = 0.1f * v + lane;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    auto timed = [&](auto late_) {
+        constexpr bool late = decltype(late_)::value;
     for (int it = 0; it < iters; it += 2) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -40,8 +43,17 @@ __global__ void __launch_bounds__(512, 2) k(unsigned long long* out, float* sink
             for (int m = 0; m < NMF; ++m) {
                 const half8 a = NRD > 0 ? q[half][m % NQ] : b[(m + 1) & 3];
                 acc[m % NCH] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[m & 3], acc[m % NCH], 0, 0, 0);
-                if (NRD > 0 && m < NRD)   // one read behind each of the first NRD MFMAs, into the other buffer
+#ifdef BURST_READS
+                if (NRD > 0 && m == 0) {  // all reads of the iteration in one burst behind the first MFMA
+#pragma unroll
+                    for (int j = 0; j < NRD; ++j) q[half ^ 1][j] = *(lds_h8)(base + ((it + half) & 7) * 8192 + j * 1024);
+                }
+#else
+                if (NRD > 0 && !late && m < NRD)   // one read behind each of the first NRD MFMAs, into the other buffer
                     q[half ^ 1][m] = *(lds_h8)(base + ((it + half) & 7) * 8192 + m * 1024);
+                if (NRD > 0 && late && m >= NMF - NRD)
+                    q[half ^ 1][m - (NMF - NRD)] = *(lds_h8)(base + ((it + half) & 7) * 8192 + (m - (NMF - NRD)) * 1024);
+#endif
                 if (IVALU > 0 && m % EVERY == EVERY - 1) {   // IVALU independent VALU instructions behind every EVERY-th MFMA
 #pragma unroll
                     for (int v = 0; v < IVALU; ++v) {
@@ -58,10 +70,31 @@ __global__ void __launch_bounds__(512, 2) k(unsigned long long* out, float* sink
 #pragma unroll
                 for (int v = 0; v < NVALU; ++v) junk = fmaxf(junk * 1.0001f, (float)(_Float16)junk) - 0.5f;
             }
+            if (RING) {   // the weight ring of the kernels: 1 KiB of LDS-DMA per wave and iteration, acquire every 2 iterations
+                const char* gsrc = wsrc + (((it + half) & 63) * 8 + (threadIdx.x >> 6)) * 1024 + lane * 16;
+                char* ldst = smem + 65536 + (((it + half) & 7) * 8 + (threadIdx.x >> 6)) * 1024;
+                if (RING & 1)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+                if (RING & 2) {
+                    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)ldst);
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "memory");
+                }
+                if ((RING & 4) && (RING & 8 ? (half == 1 && (it & 2)) : half == 1)) {   // bit 8: every 4 iterations instead of every 2
+                    if (RING & 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
             if (BAR) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    };
+#ifdef STAGGER
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0) timed(std::true_type{});   // the second wave of every SIMD
+    else timed(std::false_type{});
+#else
+    timed(std::false_type{});
+#endif
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = junk;
     for (int v = 0; v < 8; ++v) s += jv[v];
@@ -70,17 +103,19 @@ __global__ void __launch_bounds__(512, 2) k(unsigned long long* out, float* sink
     if (lane == 0) out[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
-template <int NMF, int NRD, int NCH = 8, int BAR = 0, int NVALU = 0, int IVALU = 0, int EVERY = 1, int KIND = 0>
+template <int NMF, int NRD, int NCH = 8, int BAR = 0, int NVALU = 0, int IVALU = 0, int EVERY = 1, int KIND = 0, int RING = 0>
 static void run(unsigned long long* dout, float* dsink) {
+    static char* wsrc = nullptr;
+    if (!wsrc) { hipMalloc(&wsrc, 1 << 20); hipMemset(wsrc, 0, 1 << 20); }
     const int iters = 4000, blocks = 256;
-    hipLaunchKernelGGL((k<NMF, NRD, NCH, BAR, NVALU, IVALU, EVERY, KIND>), dim3(blocks), dim3(512), 0, 0, dout, dsink, iters);
+    hipLaunchKernelGGL((k<NMF, NRD, NCH, BAR, NVALU, IVALU, EVERY, KIND, RING>), dim3(blocks), dim3(512), 0, 0, dout, dsink, iters, (const char*)wsrc);
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(blocks * 8);
     hipMemcpy(h.data(), dout, h.size() * 8, hipMemcpyDeviceToHost);
     double sum = 0;
     for (auto v : h) sum += (double)v;
     const double cyc = sum / h.size() / iters;
-    printf("NMF %2d NRD %d chains %d barrier %d bulk-valu %2d valu %d behind every %d. mfma kind %d : %7.1f cycles / iteration / wave   (MFMA pipe %4d, LDS array %4d)  pipe busy %.2f\n", NMF, NRD, NCH, BAR, NVALU, IVALU, EVERY, KIND, cyc,
+    printf("NMF %2d NRD %d chains %d barrier %d bulk-valu %2d valu %d behind every %d. mfma kind %d ring %d : %7.1f cycles / iteration / wave   (MFMA pipe %4d, LDS array %4d)  pipe busy %.2f\n", NMF, NRD, NCH, BAR, NVALU, IVALU, EVERY, KIND, RING, cyc,
            NMF * 16 * 2, NRD * 8 * 4, NMF * 32.0 / cyc, NMF * 25.6 / cyc);
 }
 
@@ -125,6 +160,19 @@ int main() {
     run<12, 0, 1, 0, 0, 1, 1, 2>(dout, dsink);
     run<12, 0, 1, 0, 0, 1, 1, 3>(dout, dsink);
     run<12, 0, 1, 0, 0, 1, 1, 4>(dout, dsink);
+    printf("with the weight ring (LDS-DMA 1 KiB per wave-iteration, vmcnt wait + barrier every 2 iterations):\n");
+    // ring bits: 1 = DMA through the builtin (visible to hipcc), 2 = DMA through inline asm, 4 = vmcnt wait + barrier
+    run<12, 8, 1, 0, 0, 0, 1, 0, 5>(dout, dsink);
+    run<12, 8, 1, 0, 0, 0, 1, 0, 6>(dout, dsink);
+    run<12, 8, 1, 0, 0, 0, 1, 0, 1>(dout, dsink);
+    run<12, 8, 1, 0, 0, 0, 1, 0, 2>(dout, dsink);
+    run<12, 8, 1, 0, 0, 0, 1, 0, 4>(dout, dsink);
+    run<12, 8, 1, 0, 0, 0, 1, 0, 12>(dout, dsink);
+    run<12, 8, 1, 0, 0, 0, 1, 0, 13>(dout, dsink);
+    run<16, 4, 2, 0, 0, 0, 1, 0, 5>(dout, dsink);
+    run<16, 4, 2, 0, 0, 0, 1, 0, 6>(dout, dsink);
+    run<16, 4, 2, 0, 0, 0, 1, 0, 2>(dout, dsink);
+    run<16, 4, 2, 0, 0, 0, 1, 0, 4>(dout, dsink);
     printf("the same VALU count, clustered:\n");
     run<12, 8, 1, 0, 0, 3, 3>(dout, dsink);
     run<12, 8, 1, 0, 0, 6, 6>(dout, dsink);
