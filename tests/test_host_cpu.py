@@ -76,3 +76,18 @@ def test_llff_poses_golden(golden):
     # the spiral is closed and looks at one focus point: consecutive views differ smoothly, first != last
     d = np.linalg.norm(np.diff(out["render_poses"][:, :3, 3], axis=0), axis=1)
     assert d.max() < 4 * np.median(d) and np.linalg.norm(out["render_poses"][0, :3, 3] - out["render_poses"][-1, :3, 3]) > 0
+
+
+def test_all_five_scene_configs_parse_and_name_their_outputs():
+    """configs/*.txt (BASELINE config 5's five scenes) in the reference's format: only the per-scene keys differ."""
+    import os
+    from tgtc_style_amd import config
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs")
+    seen = {}
+    for scene in ("fern", "flower", "horns", "orchids", "trex"):
+        a = config.parse_args(["--config", os.path.join(root, scene + ".txt")])
+        assert a.expname == scene + "_style" and a.datadir == "./data/" + scene
+        assert a.N_samples == 64 and a.N_samples_fine == 64 and a.use_viewdir and a.factor == 4
+        seen[scene] = (a.loss_coh_lambda, a.valid_factor, a.total_step)
+    assert seen == {"fern": (1e2, 3, 128001), "flower": (1e2, 3, 128000), "horns": (1e2, 2, 128001),
+                    "orchids": (5e2, 3, 128001), "trex": (1e2, 2, 128001)}

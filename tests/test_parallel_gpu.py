@@ -55,10 +55,11 @@ def _worker(rank, world, port, out_path, n_pixels, H, W):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_pixels", [40 * 400, 4001])      # an even split and a ragged one
-def test_two_ranks_equal_one(tmp_path, n_pixels):
+# an even split and a ragged one of a 400-wide frame; the WHOLE 504x378 trex frame of BASELINE config 4 (190 512 rays)
+@pytest.mark.parametrize("n_pixels,H,W", [(40 * 400, 400, 400), (4001, 400, 400), (504 * 378, 378, 504)])
+def test_two_ranks_equal_one(tmp_path, n_pixels, H, W):
     import torch.multiprocessing as mp
     out = str(tmp_path / "result.npy")
-    mp.spawn(_worker, args=(2, _free_port(), out, n_pixels, 400, 400), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, n_pixels, H, W), nprocs=2, join=True)
     same, rows, finite = np.load(out)
     assert rows == n_pixels and finite == 1 and same == 1
