@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
-"""Headline benchmark: rays/sec of the plain NeRF render (128 coarse + 64 fine samples per ray) on
-synthetic fern-shaped 400x400 frames, one process per GPU.
+"""Headline benchmark: rays/sec of the plain NeRF render (128 coarse + 64 fine samples per ray) on synthetic
+fern-shaped 400x400 frames (BASELINE.json config 2), one process per GPU.
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--sharding frames|rays]
 
-A "step" = every rank renders ONE whole 400x400 frame (160 000 rays) of its own camera pose:
-on-device ray generation (+NDC warp) -> coarse sampling -> fused PE+NeRF MLP (sigma) -> compositing ->
-inverse-CDF fine sampling -> fused PE+NeRF MLP (rgb, sigma) -> compositing, then (N > 1) one RCCL
-all-gather of the [160000, 4] RGB+depth images so that every rank holds all N frames.  Per-GPU work is
-fixed as N grows (weak scaling); `value` = N * 160000 * steps / max-over-ranks wall time.
+A "step" of the headline = every rank renders ONE whole 400x400 frame (160 000 rays) of its own camera pose:
+on-device ray generation (+NDC warp), then ONE launch of the fused ray kernel (render_fused.hip: coarse depths ->
+PE + coarse NeRF MLP -> weights -> inverse-CDF fine sampling -> PE + fine NeRF MLP -> alpha compositing; a wavefront
+owns a ray, per-sample tensors never exist), then (N > 1) one RCCL all-gather of the [160000, 4] RGB+depth images.
+Per-GPU work is fixed as N grows (weak scaling); `value` = N * 160000 * steps / max-over-ranks wall time.
+`--sharding rays` (BASELINE config 4, strong scaling): every step renders ONE frame, each rank a contiguous 1/N of
+its rays (parallel.shard_range), reassembled by the same all-gather; `value` = 160000 * steps / time.
 Inputs resident in HBM when the timed region starts: packed weights, camera poses.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (fused NeRF MLP kernel, fine pass, measured
-live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle on the host cores, N=1 only).
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      the fused ray kernel, timed live with HIP events on the launch stream around every timed step
+  cpu_baseline  the CPU oracle on the host cores (N = 1 only; bounded sample)
+  configs       N = 1 only: BASELINE configs 3 and 4 on this GPU -- the stylised ray path, the 2-D style pass,
+                and a whole 504x378 trex frame -- each with its own live-timed value
 """
 import argparse
 import json
@@ -32,13 +37,21 @@ H = W = 400
 N_COARSE, N_FINE = 128, 64
 MAC_FULL = 593408          # MACs per sample, full NeRF
 MAC_SIGMA = 491264         # MACs per sample, trunk + sigma head
-FLOP_PER_RAY = 2 * (N_COARSE * MAC_SIGMA + (N_COARSE + N_FINE) * MAC_FULL)   # 353.6 MFLOP
+MAC_STYLED = 1506912       # stylised fine sample: trunk + sigma + remap + concat MLP + style MLP
+FLOP_PER_RAY = 2 * (N_COARSE * MAC_SIGMA + (N_COARSE + N_FINE) * MAC_FULL)        # 353.6 MFLOP
+FLOP_PER_RAY_STYLED = 2 * (N_COARSE * MAC_SIGMA + (N_COARSE + N_FINE) * MAC_STYLED)   # 704.4 MFLOP
 PEAK_FP16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
-# HBM bytes of one fine-pass launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
-# WRITE_SIZE collected in separate --pmc runs; FETCH_SIZE calibrated 1:1 on the known 4-B-per-lane depth reads
-# of this kernel, see profiles/r1_pmc_summary.md).  bench.py cannot collect counters itself.
-PMC_TRAFFIC_BYTES = {"fp16x3": (102733.0 + 480000.0) * 1024, "fp16mx": (99245.0 + 480000.0) * 1024,
-                     "fp16": (85263.0 + 480000.0) * 1024}   # FETCH_SIZE + WRITE_SIZE (KB) of the fine-pass launch, profiles/r1_pmc_summary.md
+BYTES_PER_RAY = 2 * 3 * 8 + 16   # float64 origin + direction in, RGB + depth out (SURVEY 8d counts float32 rays: 24 + 16)
+# MFMA issue slots per algorithmic product: fp16x3 = hi*hi + lo*hi + hi*lo; fp16mx = 4 f16 + 2 fp6 16x16x128 per 128-deep block
+MFMA_PER_PRODUCT = {"fp16x3": 3.0, "fp16": 1.0, "fp16mx": 1.5}
+DTYPE = {"fp16x3": "f16 MFMA operands split hi+lo (3 products), f32 accumulate",
+         "fp16": "f16 MFMA operands, f32 accumulate",
+         "fp16mx": "f16 MFMA product + two block-scaled fp6 (e2m3) correction products, f32 accumulate"}
+NOTES = {"fp16": "single fp16 MFMA product: ~1e-3 per-network error, outside the 1e-3 north-star tolerance end to end",
+         "fp16x3": "fp16 hi+lo split, three MFMA products in both passes: fp32-equivalent (rgb 2e-5 against the reference's renders)",
+         "fp16x3+fp16mx": "coarse pass fp16x3, fine pass fp16 product + two block-scaled fp6 correction products: rgb 2.5e-4, "
+                          "depth 2.1e-4 against the reference's own renders, every 1e-3 parity test green "
+                          "(the inverse-CDF step amplifies coarse-pass errors only, so the coarse pass stays fp16x3)"}
 
 
 class NetArgs:
@@ -46,6 +59,7 @@ class NetArgs:
     embed_freq_coor, embed_freq_dir = 10, 4
     netdepth = netdepth_fine = 8
     netwidth = netwidth_fine = 256
+    style_D, vae_latent = 8, 32
     precision = "fp16x3"
 
 
@@ -66,6 +80,13 @@ def build_nets(precision):
         m.packed()
         nets.append(m)
     return nets
+
+
+def mfma_per_product(precision):
+    """Weighted over the coarse (sigma-only) and fine (full) passes of one ray."""
+    pc, pf = (precision.split("+") * 2)[:2]
+    fc, ff = N_COARSE * MAC_SIGMA, (N_COARSE + N_FINE) * MAC_FULL
+    return (MFMA_PER_PRODUCT[pc] * fc + MFMA_PER_PRODUCT[pf] * ff) / (fc + ff)
 
 
 def cpu_baseline(n_rays, chunk=1024):
@@ -90,34 +111,202 @@ def cpu_baseline(n_rays, chunk=1024):
                       "torch %s CPU fp32, %d threads, %.1f s" % (n_rays, chunk, torch.__version__, cores, dt)}
 
 
-def bench_style2d(args):
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ (bench.py cannot collect
+    counters itself): returns (bytes or None, provenance)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+        e = table["kernels"][kernel]
+        return e["fetch_bytes"] + e["write_bytes"], "profiles/pmc_traffic.json: %s (%s, commit %s)" % (
+            e["source"], table.get("collected", "?"), table.get("commit", "?"))
+    except (OSError, KeyError, ValueError):
+        return None, "no PMC profile committed for this kernel"
+
+
+class Timed:
+    """HIP events on the launch stream around every timed step (the ops of this package launch on torch's current
+    stream, so torch.cuda.Event brackets them); the mean is the device time of what a step enqueues."""
+
+    def __init__(self, steps):
+        self.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+
+    def run(self, i, fn):
+        self.ev[i][0].record()
+        out = fn()
+        self.ev[i][1].record()
+        return out
+
+    def mean_ms(self):
+        return float(np.mean([a.elapsed_time(b) for a, b in self.ev]))
+
+
+def time_loop(fn, steps, warmup):
+    """fn(step) -> output; returns (wall seconds of `steps` steps, mean device ms of what fn enqueues, last output)."""
+    for i in range(warmup):
+        out = fn(i)
+    torch.cuda.synchronize()
+    timed = Timed(steps)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = timed.run(i, lambda: fn(warmup + i))
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, timed.mean_ms(), out
+
+
+def bench_style2d(precision, steps, warmup):
     """Config 3's per-frame 2-D pass at 400x400: patch-embed both images, transformer, CNN decoder, resize, style
-    feature, plus one VGG encode (what train-time consumers read).  Prints ms/frame."""
+    feature, plus one VGG encode (what train-time consumers read).  ms/frame."""
     from tgtc_style_amd import style2d, synth
     mods = {}
     for name, cls, sd in (("tr", style2d.Transformer, synth.transformer_state(5)), ("pe", style2d.PatchEmbed, synth.embed_state(6)),
                           ("dec", style2d.Decoder, synth.decoder_state(7)), ("vgg", style2d.VGG, synth.vgg_state(8))):
         m = cls()
         m.load_state_dict(t_state(sd))
-        m.precision = args.precision
+        m.precision = precision
         mods[name] = m.cuda()
     net = style2d.StyTrans(mods["vgg"], mods["dec"], mods["pe"], mods["tr"])
     content = torch.rand(1, 3, H, W, device="cuda")
     style = torch.from_numpy(synth.style_image(11, H, W)).cuda()
-    times = {}
-    for label, fn in (("stylize (embed x2 + transformer + decoder + resize + feature)", lambda: style2d.stylize_frame(net, content, style)),
-                      ("vgg encode_with_intermediate", lambda: net.encode_with_intermediate(content))):
-        for _ in range(args.warmup):
-            fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            fn()
-        torch.cuda.synchronize()
-        times[label] = (time.perf_counter() - t0) / args.steps * 1e3
-    print(json.dumps({"metric": "ms/frame, 2-D style pass at 400x400 (2500 tokens)", "value": sum(times.values()),
-                      "unit": "ms", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": False,
-                      "dtype": args.precision, "data": "synthetic", "parts_ms": times}), flush=True)
+    parts = {}
+    for label, fn in (("stylize (embed x2 + transformer + decoder + resize + feature)", lambda i: style2d.stylize_frame(net, content, style)),
+                      ("vgg encode_with_intermediate", lambda i: net.encode_with_intermediate(content))):
+        parts[label] = time_loop(fn, steps, warmup)[1]
+    flop = 0.5e12   # SURVEY 8d: ~0.5 TFLOP per 400x400 frame (transformer 165 GMAC, decoder 38.6, VGG 38.6, embeds)
+    ms = sum(parts.values())
+    return {"metric": "ms/frame, 2-D style pass at 400x400 (2500 tokens): ViT + CNN decoder + VGG", "value": ms, "unit": "ms",
+            "higher_is_better": False, "steps": steps, "dtype": precision, "parts_ms": parts,
+            "roofline": {"bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flop / (ms * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, "kernel_ms": ms,
+                         "note": "all kernels of the pass together (HIP events around the frame)"}}
+
+
+def make_renderer(precision, styled):
+    from tgtc_style_amd import models, rendering, synth
+    coarse, fine = build_nets(precision)
+    style = None
+    if styled:
+        a = type("A", (NetArgs,), {"precision": precision.split("+")[-1]})
+        cm, sm = models.StyleMLP_before_concat(a), models.StyleMLP_Wild_multilayers(a)
+        cm.load_state_dict(t_state(synth.concat_state(2)))
+        sm.load_state_dict(t_state(synth.style_state(3)))
+        style = models.StylePair(cm.cuda(), sm.cuda())
+    return rendering.RayRenderer(coarse, fine, style, fused=not os.environ.get("TGTC_BENCH_CHAIN"))
+
+
+def bench_frame(precision, h, w, steps, warmup, styled=False):
+    """One GPU, one whole h x w frame per step (ray generation outside the events, the render inside)."""
+    from tgtc_style_amd import synth, utils
+    r = make_renderer(precision, styled)
+    n = h * w
+    z = torch.from_numpy(np.random.default_rng(4).standard_normal((n, 32)).astype(np.float32)).cuda() if styled else None
+    focal = synth.fern_intrinsics(h, w)
+    rays = [utils.gen_rays(h, w, focal, synth.spiral_pose(i % 120)) for i in range(2)]
+    dt, ms, out = time_loop(lambda i: r.render(*rays[i % 2], N_COARSE, N_FINE, near=0., far=1., z=z), steps, warmup)
+    assert bool(torch.isfinite(out["rgb"]).all()) and bool(torch.isfinite(out["t"]).all())
+    flop = (FLOP_PER_RAY_STYLED if styled else FLOP_PER_RAY) * n
+    return {"value": n * steps / dt, "unit": "rays/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": precision,
+            "rays_per_step": n, "kernel_ms": ms,
+            "roofline": {"bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flop / (ms * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, "kernel_ms": ms,
+                         "algorithmic_tflop_per_launch": flop / 1e12}}
+
+
+def run_headline(args, precision, rank, world, dist):
+    """The timed headline run; returns the JSON dict on rank 0, None elsewhere."""
+    from tgtc_style_amd import parallel, synth, utils
+    renderer = make_renderer(precision, False)
+    fused = renderer.fused and renderer._fused_shape(N_COARSE, N_FINE)
+    focal = synth.fern_intrinsics(H, W)
+    n_rays = H * W
+    by_rays = args.sharding == "rays" and world > 1
+    lo, hi = parallel.shard_range(n_rays, rank, world) if by_rays else (0, n_rays)
+    image = torch.empty(hi - lo, 4, device="cuda", dtype=torch.float32)
+    timed = Timed(args.steps)
+
+    def gather_frames(local):
+        out = torch.empty(world * local.shape[0], 4, device="cuda", dtype=torch.float32)
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(out, local)     # RCCL over xGMI: [160000,4] fp32 per rank
+        else:
+            dist.all_gather(list(out.chunk(world)), local)
+        return out
+
+    def step(i, timed_idx=None):
+        # frames sharding: every rank its own pose; rays sharding: all ranks the same pose, each its own pixel range
+        pose = synth.spiral_pose((i if by_rays else i * world + rank) % 120)
+        o, d = utils.gen_rays(H, W, focal, pose, first_pixel=lo, n=hi - lo)
+        render = lambda: renderer.render(o, d, N_COARSE, N_FINE, near=0., far=1.)
+        out = timed.run(timed_idx, render) if timed_idx is not None else render()
+        image[:, :3] = out["rgb"]
+        image[:, 3] = out["t"]
+        if world == 1:
+            return image
+        return parallel.gather_rows(image, n_rays, rank, world, dist) if by_rays else gather_frames(image)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        frame = step(args.warmup + i, timed_idx=i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    assert bool(torch.isfinite(frame).all())
+    if rank != 0:
+        return None
+
+    kernel_ms = timed.mean_ms()
+    rays_total = (1 if by_rays else world) * n_rays * args.steps
+    rays_launch = hi - lo
+    flop_launch = float(FLOP_PER_RAY) * rays_launch
+    achieved = flop_launch / (kernel_ms * 1e-3) / 1e12
+    pf = precision.split("+")[-1]
+    kname = "fused_render_kernel" if fused else "per-sample kernel chain"
+    traffic, provenance = pmc_traffic("fused_render_kernel:%s" % precision) if fused else (None, "chain: not profiled")
+    algo_bytes = rays_launch * BYTES_PER_RAY
+    return {
+        "metric": "rays/sec (128c+64f samples) on fern 400x400",
+        "value": rays_total / dt,
+        "unit": "rays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong" if by_rays else "weak",
+        "vs_baseline": None,
+        "dtype": DTYPE[pf] + ("" if "+" not in precision else " (fine pass; coarse pass: %s)" % precision.split("+")[0]),
+        "data": "synthetic",
+        "config": {"workload": "fern-shaped 400x400 frame, plain NeRF render (style off), 128 coarse + 64 fine samples/ray, "
+                               + ("one frame per step, rays sharded over the ranks" if by_rays else "one whole frame per rank per step")
+                               + ", seeded random-init weights",
+                   "rays_per_step": (1 if by_rays else world) * n_rays, "precision": precision,
+                   "sharding": "rays" if by_rays else "frames", "algorithmic_mflop_per_ray": FLOP_PER_RAY / 1e6,
+                   "precision_note": NOTES.get(precision, "")},
+        "roofline": {"bound": "mfma",
+                     "kernel": "%s (whole render of %d rays in one launch: PE + coarse MLP x128, fine sampling, PE + fine MLP x192, "
+                               "compositing)" % (kname, rays_launch),
+                     "achieved": achieved, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP16_TFLOPS,
+                     "traffic": traffic, "traffic_source": provenance,
+                     "algorithmic_bytes_per_launch": algo_bytes,
+                     "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
+                     "kernel_ms": kernel_ms, "algorithmic_tflop_per_launch": flop_launch / 1e12,
+                     "mfma_products_per_algorithmic_product": mfma_per_product(precision),
+                     "mfma_pipe_frac": achieved * mfma_per_product(precision) / PEAK_FP16_TFLOPS},
+        "whole_path_tflops": rays_total / dt * FLOP_PER_RAY / 1e12,
+    }
 
 
 def main():
@@ -125,14 +314,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="fp16x3",
-                    help="fp16x3 | fp16mx | fp16, or coarse+fine, e.g. fp16x3+fp16mx")
+    ap.add_argument("--precision", default="fp16x3+fp16mx",
+                    help="fp16x3 | fp16mx | fp16, or coarse+fine (default: fp16x3+fp16mx, the fastest mode that passes every 1e-3 parity test)")
+    ap.add_argument("--sharding", default="frames", choices=["frames", "rays"],
+                    help="N > 1: frames = every rank a whole frame per step (weak scaling, BASELINE config 5 style); "
+                         "rays = one frame per step, contiguous ray ranges per rank (BASELINE config 4, strong scaling)")
     ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the CPU baseline sample (0 disables)")
-    ap.add_argument("--alt-precision", default="fp16x3+fp16mx,fp16mx,fp16",
+    ap.add_argument("--alt-precision", default="fp16x3,fp16",
                     help="further precisions (comma separated) reported under `alt_precisions` ('' disables)")
-    ap.add_argument("--workload", default="plain", choices=["plain", "styled", "style2d"],
-                    help="plain = BASELINE config 2 (the headline); styled = config 3's ray path (concat + style MLPs); "
-                         "style2d = config 3's per-frame ViT + CNN decoder + VGG pass (reports ms/frame)")
+    ap.add_argument("--configs", default="styled,style2d,trex_rays",
+                    help="N = 1: further BASELINE configs measured after the headline and reported under `configs` ('' disables)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,155 +334,43 @@ def main():
     # one rank per GPU; TGTC_DIST_BACKEND=gloo lets several ranks share one GPU for functional rehearsals of the N>1 path
     backend = os.environ.get("TGTC_DIST_BACKEND", "nccl")
     local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
-    torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1:   # the process group comes up before the first HIP call of this process
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+    torch.cuda.set_device(local)
 
-    if args.workload == "style2d":
-        return bench_style2d(args)
-    line = run_rays(args, args.precision, rank, world, dist)
-    alts = [p for p in args.alt_precision.split(",") if p and p != args.precision] if args.workload == "plain" else []
-    alt_lines = [run_rays(args, p, rank, world, dist) for p in alts]   # every rank joins the collectives
+    line = run_headline(args, args.precision, rank, world, dist)
+    alts = [p for p in args.alt_precision.split(",") if p and p != args.precision]
+    alt_lines = [run_headline(args, p, rank, world, dist) for p in alts]   # every rank joins the collectives
     if rank == 0:
-        notes = {"fp16": "single fp16 MFMA product: ~1e-3 per-network error, outside the 1e-3 north-star tolerance end to "
-                         "end; the headline value above is the parity mode",
-                 "fp16mx": "fp16 product + two block-scaled fp6 correction products: rgb within 1e-3 of the reference's own "
-                           "renders, composited depth 2e-3; block scaling makes the margin weight dependent, so the "
-                           "element-wise fp16x3 split stays the headline parity mode",
-                 "fp16x3": "fp16 hi+lo split, three MFMA products: fp32-equivalent",
-                 "fp16x3+fp16mx": "coarse pass fp16x3, fine pass fp16mx: rgb 2.5e-4 and depth 2.1e-4 against the reference's own "
-                                  "renders (the inverse-CDF step amplifies coarse-pass errors only); block-scaling caveat of fp16mx "
-                                  "applies to the fine network"}
         for p, alt in zip(alts, alt_lines):
             entry = {k: alt[k] for k in ("value", "ms_per_step", "dtype")}
             entry.update(precision=p, roofline_frac=alt["roofline"]["frac"], kernel_ms=alt["roofline"]["kernel_ms"],
-                         mfma_pipe_frac=alt["roofline"]["mfma_pipe_frac"], note=notes.get(p, ""))
+                         mfma_pipe_frac=alt["roofline"]["mfma_pipe_frac"], note=NOTES.get(p, ""))
             line.setdefault("alt_precisions", []).append(entry)
-            if p == "fp16":
-                line["alt_precision"] = entry
-        if world == 1 and args.cpu_rays > 0 and args.workload == "plain":
-            line["cpu_baseline"] = cpu_baseline(args.cpu_rays)
+        if world == 1:
+            short = max(2, min(args.steps, 3))
+            cfg = {}
+            wanted = [c for c in args.configs.split(",") if c]
+            if "styled" in wanted:      # BASELINE config 3, ray path: the stylised chain (NeRF + concat MLP + style MLP)
+                cfg["styled"] = dict(bench_frame("fp16x3", H, W, short, 1, styled=True),
+                                     metric="rays/sec (128c+64f) on fern 400x400, stylised (concat + style MLPs)")
+            if "style2d" in wanted:     # BASELINE config 3, per-frame ViT + CNN decoder + VGG pass
+                cfg["style2d"] = bench_style2d("fp16x3", short, 1)
+            if "trex_rays" in wanted:   # BASELINE config 4's frame on one GPU (its 8 ray ranges are this frame's slices)
+                cfg["trex_rays"] = dict(bench_frame(args.precision, 378, 504, short, 1),
+                                        metric="rays/sec (128c+64f) on a whole trex 504x378 frame (190512 rays), one GPU")
+            if cfg:
+                line["configs"] = cfg
+            if args.cpu_rays > 0:
+                line["cpu_baseline"] = cpu_baseline(args.cpu_rays)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
-
-
-def run_rays(args, precision, rank, world, dist):
-    """One timed run of the plain or stylised ray workload; returns the JSON dict on rank 0, None elsewhere."""
-    from tgtc_style_amd import hip, rendering, synth, utils
-    lib = hip.load()
-    coarse, fine = build_nets(precision)
-    renderer = rendering.RayRenderer(coarse, fine)
-    z = None
-    if args.workload == "styled":
-        from tgtc_style_amd import models
-        a = type("A", (NetArgs,), {"precision": precision, "style_D": 8, "vae_latent": 32})
-        cm, sm = models.StyleMLP_before_concat(a), models.StyleMLP_Wild_multilayers(a)
-        cm.load_state_dict(t_state(synth.concat_state(2)))
-        sm.load_state_dict(t_state(synth.style_state(3)))
-        renderer = rendering.RayRenderer(coarse, fine, models.StylePair(cm.cuda(), sm.cuda()))
-        z = torch.from_numpy(np.random.default_rng(4).standard_normal((H * W, 32)).astype(np.float32)).cuda()
-    focal = synth.fern_intrinsics(H, W)
-    n_rays = H * W
-    image = torch.empty(n_rays, 4, device="cuda", dtype=torch.float32)
-    gathered = torch.empty(world * n_rays, 4, device="cuda", dtype=torch.float32) if world > 1 else None
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b in ev:   # create the underlying hipEvents before handing their handles to the library
-        a.record(); b.record()
-    torch.cuda.synchronize()
-
-    def step(i, timed_idx=None):
-        pose = synth.spiral_pose((i * world + rank) % 120)
-        o, d = utils.gen_rays(H, W, focal, pose)
-        if timed_idx is not None:
-            hip.check(lib.tgtc_time_next_nerf_launch(1, ev[timed_idx][0].cuda_event, ev[timed_idx][1].cuda_event))
-        out = renderer.render(o, d, N_COARSE, N_FINE, near=0., far=1., z=z)
-        image[:, :3] = out["rgb"]
-        image[:, 3] = out["t"]
-        if world > 1:
-            if dist.get_backend() == "nccl":
-                dist.all_gather_into_tensor(gathered, image)     # RCCL over xGMI: [160000,4] fp32 per rank
-            else:
-                dist.all_gather(list(gathered.chunk(world)), image)
-
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, timed_idx=i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
-
-    assert bool(torch.isfinite(image).all()) or os.environ.get("TGTC_BENCH_NOCHECK")   # (timing experiments with broken arithmetic)
-    if args.workload == "styled":
-        if rank == 0:
-            flop_ray = 2 * (N_COARSE * MAC_SIGMA + (N_COARSE + N_FINE) * 1506912)     # SURVEY 8d: 704.4 MFLOP/ray
-            return ({"metric": "rays/sec (128c+64f samples) on fern 400x400, stylised (concat + style MLPs)",
-                              "value": world * n_rays * args.steps / dt, "unit": "rays/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
-                              "dtype": precision, "config": {"workload": "fern 400x400 stylised render, 128c+64f",
-                                                                  "algorithmic_mflop_per_ray": flop_ray / 1e6},
-                              "whole_path_tflops": world * n_rays * args.steps / dt * flop_ray / 1e12})
-        return None
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-
-    if rank == 0:
-        rays_total = world * n_rays * args.steps
-        flop_launch = 2.0 * MAC_FULL * n_rays * (N_COARSE + N_FINE)      # algorithmic flop of one fine-pass launch
-        achieved = flop_launch / (kernel_ms * 1e-3) / 1e12
-        # MFMA issue slots per algorithmic product: fp16mx = 4 f16 + 2 fp6 16x16x128 instructions per 128-deep block
-        fine_prec = precision.split("+")[-1]          # the timed kernel is the fine pass
-        mfma_per_product = {"fp16x3": 3.0, "fp16": 1.0, "fp16mx": 1.5}[fine_prec]
-        line = {
-            "metric": "rays/sec (128c+64f samples) on fern 400x400",
-            "value": rays_total / dt,
-            "unit": "rays/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": {"fp16x3": "f16 MFMA operands split hi+lo (3 products), f32 accumulate",
-                      "fp16": "f16 MFMA operands, f32 accumulate",
-                      "fp16mx": "f16 MFMA product + two block-scaled fp6 (e2m3) correction products, f32 accumulate"}[fine_prec]
-                     + ("" if "+" not in precision else " (fine pass; coarse pass: %s)" % precision.split("+")[0]),
-            "data": "synthetic",
-            "config": {"workload": "fern-shaped 400x400 frame, plain NeRF render (style off), 128 coarse + 64 fine "
-                                   "samples/ray, one whole frame per rank per step, seeded random-init weights",
-                       "rays_per_step": world * n_rays, "precision": precision, "sharding": "frames",
-                       "algorithmic_mflop_per_ray": FLOP_PER_RAY / 1e6},
-            "roofline": {"bound": "mfma", "kernel": ("nerf_mx_kernel<FULL>" if fine_prec == "fp16mx" else "nerf_mlp_kernel<FULL>") + " (fine pass: PE + 12 dense layers, %d samples)"
-                                                   % (n_rays * (N_COARSE + N_FINE)),
-                         "achieved": achieved, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP16_TFLOPS, "traffic": PMC_TRAFFIC_BYTES.get(fine_prec),
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/)",
-                         "algorithmic_bytes_per_launch": n_rays * (N_COARSE + N_FINE) * 20,
-                         "kernel_ms": kernel_ms, "algorithmic_tflop_per_launch": flop_launch / 1e12,
-                         "mfma_products_per_algorithmic_product": mfma_per_product,
-                         "mfma_pipe_frac": achieved * mfma_per_product / PEAK_FP16_TFLOPS},
-            "whole_path_tflops": rays_total / dt * FLOP_PER_RAY / 1e12,
-        }
-        return line
-    return None
 
 
 if __name__ == "__main__":

@@ -94,15 +94,6 @@ int tgtc_nerf_mlp_forward(const tgtc_net* net, const float* pts_enc, const float
 int tgtc_nerf_forward_rays(const tgtc_net* net, const double* rays_o, const double* rays_d, const float* ts,
                            int64_t R, int N, float* rgb, float* sigma, void* stream);
 
-/* Measurement hook: record the two hipEvent_t (passed as void*) on the launch stream immediately before / after
- * the NEXT fused NeRF kernel launch issued by the calling thread (full=1: the rgb+sigma kernel, full=0: the
- * sigma-only kernel of a fused render's coarse pass).  One-shot.  Used by bench.py for the roofline figure. */
-int tgtc_time_next_nerf_launch(int full, void* start_event, void* stop_event);
-
-/* Diagnostics: while buf != NULL, the first 64 workgroups of every fused NeRF launch of the calling thread write
- * s_memtime stamps of their phase boundaries into buf ([64][8 waves][32] uint64).  Never set in production. */
-int tgtc_debug_set_stamps(void* buf);
-
 /* ------------------------------------------------------------------ a6: alpha compositing
  * utils.py:354-386 alpha_composition with sigma_noise_std=0, white_bkgd=False.  weights may be NULL. */
 int tgtc_composite(const float* rgb, const float* sigma, const float* ts, int64_t R, int N,
@@ -116,13 +107,25 @@ int tgtc_sample_fine(const double* rays_o, const double* rays_d, const float* ts
 
 /* ------------------------------------------------------------------ fused plain render (cal_geometry chain)
  * rendering.py:27-51: coarse sample -> NeRF(coarse) -> composite -> fine sample -> NeRF(fine) -> composite.
- * workspace: device scratch of at least tgtc_render_workspace_bytes(R, n_coarse, n_fine) bytes.
- * jitter: float [R,n_coarse] or NULL.  Outputs: rgb float [R,3], depth float [R]; optional coarse outputs. */
+ * jitter: float [R,n_coarse] or NULL.  Outputs: rgb float [R,3], depth float [R]; optional coarse outputs.
+ *
+ * tgtc_render_rays_plain runs the whole chain as ONE persistent kernel (a wavefront owns a ray; per-sample
+ * tensors never exist; HBM sees 48 B of ray in and 16 B of pixel out) whenever
+ *   - n_coarse and n_coarse+n_fine are multiples of 16 (32 in TGTC_PREC_FP16), n_coarse <= 192, total <= 256,
+ *   - the precisions are fp16x3+fp16x3, fp16x3 (coarse) + fp16_fp6 (fine), or fp16+fp16,
+ *   - the coarse image is not requested (rgb_coarse == t_coarse == NULL);
+ * then `workspace` is not touched and may be NULL.  Otherwise it falls back to
+ * tgtc_render_rays_plain_chain: the same arithmetic as a sequence of per-sample kernels through
+ * workspace (device scratch of at least tgtc_render_workspace_bytes(R, n_coarse, n_fine) bytes). */
 size_t tgtc_render_workspace_bytes(int64_t R, int n_coarse, int n_fine);
 int tgtc_render_rays_plain(const tgtc_net* coarse, const tgtc_net* fine, const double* rays_o, const double* rays_d,
                            int64_t R, int n_coarse, int n_fine, float near_, float far_, const float* jitter,
                            void* workspace, size_t workspace_bytes,
                            float* rgb_fine, float* t_fine, float* rgb_coarse, float* t_coarse, void* stream);
+int tgtc_render_rays_plain_chain(const tgtc_net* coarse, const tgtc_net* fine, const double* rays_o,
+                                 const double* rays_d, int64_t R, int n_coarse, int n_fine, float near_, float far_,
+                                 const float* jitter, void* workspace, size_t workspace_bytes, float* rgb_fine,
+                                 float* t_fine, float* rgb_coarse, float* t_coarse, void* stream);
 
 /* ------------------------------------------------------------------ a8: latent table
  * models.py:490-506 StyleLatents_variational.forward.  latents float [S,F,D] device, mu float [S,D] device,

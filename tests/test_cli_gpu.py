@@ -113,3 +113,38 @@ def test_cli_reloads_reference_checkpoints(tmp_path):
     assert np.abs(a - b).max() > 8                                     # other style / latent weights: a different image
     # --no_reload ignores the files again (train_tgtcs.py:63)
     assert os.path.basename(train_tgtcs.main(base + ["--no_reload"])) == "render_valid_0"
+
+
+def _cli_rank(rank, world, port, argv, backend_env):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), TGTC_DIST_BACKEND=backend_env)
+    from tgtc_style_amd import train_tgtcs
+    train_tgtcs.main(argv)
+
+
+@pytest.mark.parametrize("shard", ["frames", "rays"])
+def test_cli_two_ranks_write_the_single_rank_images(tmp_path, shard):
+    """The CLI under torchrun-style environment variables (two ranks, gloo rendezvous on 127.0.0.1, both on the test
+    box's one GPU): --shard frames = images round-robin with rank-local files, --shard rays = contiguous ray ranges of
+    every image + one all-gather, rank 0 writes.  Either way the PNG files are byte-identical to the one-rank run."""
+    import socket
+    import torch.multiprocessing as mp
+    from tgtc_style_amd import train_tgtcs
+    common = ["--config", os.path.join(ROOT, "configs", "fern.txt"), "--synthetic", "--synthetic_hw", "20", "--synthetic_frames", "3",
+              "--chunk", "1024", "--batch_size", "128", "--render_valid_style"]
+    one = train_tgtcs.main(common + ["--basedir", str(tmp_path / "one")])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: os.environ.get(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TGTC_DIST_BACKEND")}
+    try:
+        mp.spawn(_cli_rank, args=(2, port, common + ["--basedir", str(tmp_path / "two"), "--shard", shard], "gloo"), nprocs=2, join=True)
+    finally:
+        for k, v in env.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    two = os.path.join(str(tmp_path / "two"), os.path.relpath(one, str(tmp_path / "one")))
+    names = sorted(os.listdir(one))
+    assert len(names) == 6 and sorted(os.listdir(two)) == names
+    for n in names:
+        with open(os.path.join(one, n), "rb") as a, open(os.path.join(two, n), "rb") as b:
+            assert a.read() == b.read(), n

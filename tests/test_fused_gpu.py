@@ -1,0 +1,98 @@
+"""GPU: the single persistent ray kernel behind tgtc_render_rays_plain (render_fused.hip) against
+  * the reference's own renders (golden g8: cal_geometry chain on 64 rays, 128c+64f and 64c+64f, with and without
+    stratified jitter), at the north-star tolerance 1e-3;
+  * the chain of per-sample kernels (tgtc_render_rays_plain_chain) on the same rays: same network arithmetic, the
+    compositing scan associates differently, so agreement is to float32 rounding;
+  * itself under re-sharding: any sub-range of rays, any ray count (not a multiple of the 8 rays of a workgroup
+    step), reproduces the same bits -- rays are independent and a ray's arithmetic does not depend on the wave,
+    workgroup or launch that renders it.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tgtc_style_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def T(sd):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+
+class Args:
+    use_viewdir, act_type = True, "relu"
+    embed_freq_coor, embed_freq_dir = 10, 4
+    netdepth = netdepth_fine = 8
+    netwidth = netwidth_fine = 256
+    precision = "fp16x3"
+
+
+def renderer(prec_c, prec_f, fused):
+    from tgtc_style_amd import models, rendering
+    nets = []
+    for (seed, mode), prec in zip(((0, "coarse"), (1, "fine")), (prec_c, prec_f)):
+        m = models.StyleNerf(type("A", (Args,), {"precision": prec}), mode=mode)
+        m.load_state_dict(T(synth.nerf_state(seed)))
+        nets.append(m.cuda())
+    return rendering.RayRenderer(nets[0], nets[1], fused=fused)
+
+
+PAIRS = [("fp16x3", "fp16x3"), ("fp16x3", "fp16mx"), ("fp16", "fp16")]
+LIMIT = {"fp16x3": 1e-3, "fp16mx": 1e-3, "fp16": 2e-2}      # against the reference (fp16 is the documented fast mode)
+# fused vs chain: the two composite scans associate differently, so the coarse weights differ in the last bit and the
+# fine depths move by ~1e-7.  fp16x3 follows such a perturbation smoothly (4e-7 end to end); the fp6 roundings of fp16mx
+# and the fp16 roundings of the fast mode turn it into their own rounding noise.
+VS_CHAIN = {"fp16x3": 1e-5, "fp16mx": 1e-4, "fp16": 2e-3}
+
+
+@pytest.mark.parametrize("prec_c,prec_f", PAIRS)
+@pytest.mark.parametrize("nc,nf", [(128, 64), (64, 64)])
+def test_fused_render_golden(golden, prec_c, prec_f, nc, nf):
+    g = golden("g8_end_to_end")
+    tag = "_%dc%df" % (nc, nf)
+    ro, rd = torch.from_numpy(g["rays_o" + tag]).cuda(), torch.from_numpy(g["rays_d" + tag]).cuda()
+    fused, chain = renderer(prec_c, prec_f, True), renderer(prec_c, prec_f, False)
+    assert fused._fused_shape(nc, nf)
+    for jt, jit in (("", None), ("_jit", torch.from_numpy(g["jit" + tag]).cuda())):
+        a = fused.render(ro, rd, nc, nf, near=0., far=1., jitter=jit)
+        b = chain.render(ro, rd, nc, nf, near=0., far=1., jitter=jit)
+        e_chain = max(float((a["rgb"] - b["rgb"]).abs().max()), float((a["t"] - b["t"]).abs().max()))
+        e_ref = 0.0
+        if jit is None:      # the reference's plain chain (cal_geometry) never jitters; the jittered case is pinned by the chain
+            e_ref = max(float((a["rgb"].cpu() - torch.from_numpy(g["plain_rgb" + tag])).abs().max()),
+                        float((a["t"].cpu() - torch.from_numpy(g["plain_t" + tag])).abs().max()))
+        print(prec_c, prec_f, tag, jt, "vs reference %.2e  vs chain %.2e" % (e_ref, e_chain))
+        assert e_ref <= LIMIT[prec_f] and e_chain <= VS_CHAIN[prec_f]
+
+
+@pytest.mark.parametrize("prec_c,prec_f", PAIRS)
+def test_fused_render_ray_counts_and_shards(prec_c, prec_f):
+    from tgtc_style_amd import utils
+    H = W = 400
+    ro, rd = utils.gen_rays(H, W, synth.fern_intrinsics(H, W), synth.spiral_pose(3), first_pixel=33 * W, n=2077)
+    r = renderer(prec_c, prec_f, True)
+    whole = r.render(ro, rd, 128, 64)
+    assert bool(torch.isfinite(whole["rgb"]).all()) and bool(torch.isfinite(whole["t"]).all())
+    assert float(whole["rgb"].min()) >= 0 and float(whole["rgb"].max()) <= 1 + 1e-5
+    for lo, hi in ((0, 1), (5, 18), (1000, 2077), (7, 2056)):      # 1, 13, 1077, 2049 rays
+        part = r.render(ro[lo:hi].contiguous(), rd[lo:hi].contiguous(), 128, 64)
+        assert torch.equal(part["rgb"], whole["rgb"][lo:hi]) and torch.equal(part["t"], whole["t"][lo:hi]), (lo, hi)
+    chain = renderer(prec_c, prec_f, False).render(ro, rd, 128, 64)
+    e = max(float((chain["rgb"] - whole["rgb"]).abs().max()), float((chain["t"] - whole["t"]).abs().max()))
+    print(prec_c, prec_f, "2077 rays, fused vs chain %.2e" % e)
+    assert e <= VS_CHAIN[prec_f]
+
+
+def test_fused_falls_back_to_the_chain():
+    """Sample counts the ray kernel does not tile (n_coarse not a multiple of 16) and requests for the coarse image run
+    the per-sample chain behind the same entry point."""
+    from tgtc_style_amd import utils
+    r = renderer("fp16x3", "fp16x3", True)
+    assert not r._fused_shape(100, 28) and r._fused_shape(128, 64) and not r._fused_shape(208, 48)
+    ro, rd = utils.gen_rays(16, 16, synth.fern_intrinsics(16, 16), synth.spiral_pose(1))
+    a = r.render(ro, rd, 100, 28)
+    b = renderer("fp16x3", "fp16x3", False).render(ro, rd, 100, 28)
+    assert torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["t"], b["t"])
+    c = r.render(ro, rd, 128, 64, want_coarse=True)
+    assert "rgb_coarse" in c and bool(torch.isfinite(c["rgb_coarse"]).all())

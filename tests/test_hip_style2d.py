@@ -178,3 +178,52 @@ def test_stylize_frames_writes_reference_layout(tmp_path, nets):
     rows = [style2d.stylize_frame(net, f, style)[1].cpu().numpy().reshape(1024) for f in frames]
     assert np.allclose(z["style_features"][0], np.mean(rows, 0), rtol=1e-5, atol=1e-6)
     assert np.array_equal(feats, z["style_features"])
+
+
+def test_transformer_render_driver_from_disk(tmp_path):
+    """The disk-level driver (reference trans_test.py:55-179): the four checkpoint layouts the reference writes
+    (vgg_normalised.pth = the FULL vgg Sequential's state dict, decoder.pth = {'decoder': ..}, transformer_iter_N.pth /
+    embedding_iter_N.pth = bare state dicts, the newest by file name wins), a directory of rendered frames (depth /
+    geometry files skipped), one style image; NNN.jpg counted from 001 and stylized_data.npz with the dataset's keys."""
+    from PIL import Image
+    from tgtc_style_amd import style2d, trans_test
+    t = lambda sd: {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    save_dir = tmp_path / "pretrained"
+    save_dir.mkdir()
+    vgg_sd = t(synth.vgg_state(8))
+    vgg_sd.update({"31.weight": torch.zeros(512, 512, 3, 3), "31.bias": torch.zeros(512)})      # layers behind [:31] are ignored
+    torch.save(vgg_sd, save_dir / "vgg_normalised.pth")
+    torch.save({"decoder": t(synth.decoder_state(7)), "step": 5}, save_dir / "decoder.pth")
+    torch.save(t(synth.transformer_state(55)), save_dir / "transformer_iter_100.pth")            # older: must lose
+    torch.save(t(synth.transformer_state(5)), save_dir / "transformer_iter_200.pth")
+    torch.save(t(synth.embed_state(6)), save_dir / "embedding_iter_200.pth")
+    frames, styles = tmp_path / "nerf_gen_data2", tmp_path / "style"
+    frames.mkdir(), styles.mkdir()
+    rng = np.random.default_rng(3)
+    h, w = 40, 56
+    content = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(2)]
+    for i, a in enumerate(content):
+        Image.fromarray(a).save(frames / ("rgb_%05d.png" % i))
+        Image.fromarray(a[..., 0]).save(frames / ("depth_%05d.png" % i))                         # skipped (:82)
+    np.savez(frames / "geometry_00000.npz", x=np.zeros(1))                                       # skipped
+    style = rng.integers(0, 256, (64, 80, 3), dtype=np.uint8)
+    Image.fromarray(style).save(styles / "starry.png")
+    out = tmp_path / "stylized_gen_4.0"
+    feat = trans_test.transformer_render(str(frames), str(styles), str(out), save_ext=".png", vgg=str(save_dir / "vgg_normalised.pth"),
+                                         save_dir=str(save_dir), decoder_path=str(save_dir / "decoder.pth"))
+    assert sorted(os.listdir(out)) == ["001.png", "002.png", "stylized_data.npz"]
+    d = trans_test.read_stylized_data(str(tmp_path), 4.0)
+    assert d["style_names"] == {"starry": 0} and d["style_images"].shape == (1, 512, 512, 3) and d["style_features"].shape == (1, 1024)
+    assert np.array_equal(d["style_features"], feat) and str(d["style_paths"]).endswith("starry.png")
+    # the same frames through the modules directly (the newest transformer checkpoint = seed 5)
+    net = trans_test.load_network(str(save_dir / "vgg_normalised.pth"), str(save_dir), str(save_dir / "decoder.pth"))
+    crop = np.asarray(trans_test._center_crop(Image.fromarray(style), h, w))
+    rows = []
+    for i, a in enumerate(content):
+        c = torch.from_numpy(a).permute(2, 0, 1).float().div(255).cuda()[None]
+        s = torch.from_numpy(crop.copy()).permute(2, 0, 1).float().div(255).cuda()[None]
+        image, f, _ = style2d.stylize_frame(net, c, s)
+        img8 = image[0].mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).cpu().numpy()
+        assert np.array_equal(np.asarray(Image.open(out / ("%03d.png" % (i + 1)))), img8) and img8.shape == (h, w, 3)
+        rows.append(f.float().cpu().numpy().reshape(1024))
+    assert np.allclose(feat[0], np.mean(rows, 0), rtol=1e-6, atol=1e-7)

@@ -1,0 +1,95 @@
+"""CPU: host-side file formats either side of the hot path -- the image side of the
+LLFF loader and the stylized_data.npz / image-transform plumbing of the 2-D pass driver.  No GPU, no compute kernels."""
+import os
+
+import numpy as np
+import pytest
+
+from tgtc_style_amd import llff_images, trans_test
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+def _scene(tmp_path, n=3, h=24, w=36, with_minified=None):
+    rng = np.random.default_rng(0)
+    base = tmp_path / "scene"
+    (base / "images").mkdir(parents=True)
+    imgs = []
+    for i in range(n):
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        PIL.fromarray(a).save(base / "images" / ("img_%02d.png" % i))
+        imgs.append(a)
+    poses = rng.standard_normal((n, 3, 5))
+    poses[:, 0, 4], poses[:, 1, 4], poses[:, 2, 4] = h, w, 30.0
+    np.save(base / "poses_bounds.npy", np.concatenate([poses.reshape(n, 15), np.tile([[1.0, 9.0]], (n, 1))], 1))
+    if with_minified:
+        d = base / ("images_%s" % with_minified)
+        d.mkdir()
+        small = [rng.integers(0, 256, (h // 2, w // 2, 4), dtype=np.uint8) for _ in range(n)]     # RGBA: alpha is dropped
+        for i, a in enumerate(small):
+            PIL.fromarray(a).save(d / ("img_%02d.png" % i))
+        return str(base), imgs, small
+    return str(base), imgs, None
+
+
+def test_load_data_uses_an_existing_minified_directory_exactly(tmp_path):
+    base, _, small = _scene(tmp_path, with_minified=2)
+    poses, bds, imgs = llff_images.load_data(base, factor=2)
+    assert poses.shape == (3, 5, 3) and bds.shape == (2, 3) and imgs.shape == (12, 18, 3, 3)
+    # load_llff.py:95-97: (H, W) of the table = the minified image, focal / factor
+    assert np.all(poses[0, 4] == 12) and np.all(poses[1, 4] == 18) and np.allclose(poses[2, 4], 15.0)
+    for i, a in enumerate(small):
+        assert np.array_equal(imgs[..., i], a[..., :3] / 255.)           # load_llff.py:108: imread(f)[..., :3] / 255.
+    images = llff_images.load_images(base, 2)
+    assert images.shape == (3, 12, 18, 3) and images.dtype == np.float32
+
+
+def test_minify_creates_the_cache_once(tmp_path):
+    base, full, _ = _scene(tmp_path)
+    d = llff_images.minify(base, 2)
+    files = sorted(os.listdir(d))
+    assert d.endswith("images_2") and files == ["img_00.png", "img_01.png", "img_02.png"]
+    assert PIL.open(os.path.join(d, files[0])).size == (18, 12)
+    stamp = os.path.getmtime(os.path.join(d, files[0]))
+    assert llff_images.minify(base, 2) == d and os.path.getmtime(os.path.join(d, files[0])) == stamp
+    poses, bds = llff_images.load_data(base, factor=2, load_imgs=False)
+    assert np.all(poses[0, 4] == 12) and np.allclose(poses[2, 4], 15.0)
+    # factor None: the full-size images, table untouched apart from (H, W)
+    poses, bds, imgs = llff_images.load_data(base, factor=None)
+    assert imgs.shape == (24, 36, 3, 3) and np.array_equal(imgs[..., 1], full[1] / 255.) and np.allclose(poses[2, 4], 30.0)
+
+
+def test_mismatch_between_images_and_poses_is_an_error(tmp_path):
+    base, _, _ = _scene(tmp_path, with_minified=2)
+    os.remove(os.path.join(base, "images_2", "img_02.png"))
+    with pytest.raises(ValueError):
+        llff_images.load_data(base, factor=2)
+
+
+def test_stylized_data_round_trip(tmp_path):
+    """The npz the 2-D driver writes (trans_test.py:179) read back the way the datasets do (dataset.py:437-440)."""
+    out = tmp_path / "data" / "stylized_gen_4.0"
+    out.mkdir(parents=True)
+    feats = np.arange(1024, dtype=np.float32)[None]
+    style = np.random.default_rng(1).random((1, 512, 512, 3)).astype(np.float32)
+    np.savez(os.path.join(out, "stylized_data"), style_names={"starry": 0}, style_paths="style/starry.jpg",
+             style_images=style, style_features=feats)
+    d = trans_test.read_stylized_data(str(tmp_path / "data"), 4.0)
+    assert d["style_names"] == {"starry": 0} and d["style_num"] == 1 and str(d["style_paths"]) == "style/starry.jpg"
+    assert np.array_equal(d["style_features"], feats) and np.array_equal(d["style_images"], style)
+    assert trans_test.read_stylized_data(str(tmp_path / "data"), 8.0) is None
+
+
+def test_image_transforms_match_torchvision_semantics():
+    a = np.arange(5 * 7 * 3, dtype=np.uint8).reshape(5, 7, 3)
+    img = PIL.fromarray(a)
+    t = trans_test._to_tensor(img)
+    assert t.shape == (3, 5, 7) and float(t[1, 2, 3]) == a[2, 3, 1] / np.float32(255.0)
+    # CenterCrop inside the image: offsets int(round((H - h) / 2)), int(round((W - w) / 2))
+    c = np.asarray(trans_test._center_crop(img, 3, 4))
+    assert np.array_equal(c, a[1:4, 2:6])
+    # crop window larger than the image: centred, black outside
+    c = np.asarray(trans_test._center_crop(img, 7, 9))
+    assert c.shape == (7, 9, 3) and np.array_equal(c[1:6, 1:8], a) and not c[0].any() and not c[:, 0].any()
+    s = trans_test.style_image_array.__doc__
+    assert "512" in s

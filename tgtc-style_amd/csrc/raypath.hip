@@ -7,19 +7,13 @@
 // order (no FMA contraction where the reference has separate roundings) so float64 outputs agree to
 // the last bits and float32 outputs to ~1 ulp.
 #include "common.h"
+#include "raymarch_dev.h"
 
 // The reference evaluates these formulas with separate multiplies and adds (numpy / ATen CPU);
 // keep the same roundings.
 #pragma clang fp contract(off)
 
 namespace tgtc {
-
-__device__ __forceinline__ float linspace01(int i, int n) {
-    // torch.linspace(0,1,n) float32 (ATen RangeFactoriesKernel: first half start+step*i, second half
-    // end-step*(n-1-i), each with a single rounding).
-    const float step = 1.0f / (float)(n - 1);
-    return (i < n / 2) ? step * (float)i : __fmaf_rn(-step, (float)(n - 1 - i), 1.0f);
-}
 
 // ------------------------------------------------------------------------------------------- rays
 // reference dataset.py:33-42 + dataset.py:44-61
@@ -80,19 +74,6 @@ __global__ void __launch_bounds__(256) gen_rays_kernel(RayGenArgs a, double* __r
 
 // ------------------------------------------------------------------------------- coarse sampling
 // reference utils.py:509-531
-__device__ __forceinline__ float coarse_t(int i, int n, float near_, float far_) {
-    float t = linspace01(i, n);
-    return t * (far_ - near_) + near_;  // utils.py:514
-}
-
-__device__ __forceinline__ float coarse_t_jittered(int i, int n, float near_, float far_, float u) {
-    // utils.py:521-524: interval between the midpoints to the neighbours
-    const float t = coarse_t(i, n, near_, far_);
-    const float lo = (i == 0) ? t : (t + coarse_t(i - 1, n, near_, far_)) / 2.0f;
-    const float hi = (i == n - 1) ? t : (coarse_t(i + 1, n, near_, far_) + t) / 2.0f;
-    return lo + (hi - lo) * u;
-}
-
 __global__ void __launch_bounds__(256) sample_coarse_kernel(const double* __restrict__ rays_o,
                                                             const double* __restrict__ rays_d, long long R, int N,
                                                             float near_, float far_, const float* __restrict__ jitter,
@@ -130,44 +111,45 @@ __global__ void __launch_bounds__(256) posenc_kernel(const T* __restrict__ x, lo
 
 // -------------------------------------------------------------------------------------- composite
 // reference utils.py:354-386.  One wavefront per ray; lane l owns the contiguous run of samples
-// [l*C, l*C+C), C = ceil(N/64): a serial product inside the run, then a wave-exclusive product scan
-// over the lane totals, then four weighted wave reductions.
+// [l*C, l*C+C), C = ceil(N/64).  The transmittance is the reference's SEQUENTIAL product, sample after sample in
+// float64 and rounded to float32 per element (torch.cumprod on the CPU accumulates in acc_type<float> = double):
+// every lane walks the whole chain with the `keep` factors broadcast lane by lane, so the weights do not depend
+// on the tiling (raymarch_dev.h composite_tile computes the same chain 16 samples at a time).  Then four weighted
+// wave reductions.
 template <int C>
 __device__ __forceinline__ void composite_wave(const float* __restrict__ rgb, const float* __restrict__ sigma,
                                                const float* __restrict__ ts, int N, float* rgb_exp, float* t_exp,
                                                float* weights) {
     const int lane = threadIdx.x & 63;
-    float alpha[C], tv[C], keep = 1.0f;
+    float alpha[C], tv[C], keep[C];
 #pragma unroll
     for (int k = 0; k < C; ++k) {
         const int i = lane * C + k;
-        alpha[k] = 0.0f;
-        tv[k] = 0.0f;
+        alpha[k] = 0.0f, tv[k] = 0.0f, keep[k] = 1.0f;
         if (i < N) {
             const float t0 = ts[i];
             const float delta = (i + 1 < N) ? ts[i + 1] - t0 : 1e10f;       // utils.py:367-369
             const float dens = fmaxf(fmaxf(sigma[i], 0.0f), 0.0f);          // relu(relu(.)) :365,:376
             alpha[k] = 1.0f - expf(-dens * delta);
             tv[k] = t0;
-            keep = keep * (1.0f - alpha[k] + 1e-10f);                       // :378
+            keep[k] = 1.0f - alpha[k] + 1e-10f;                             // :378
         }
     }
-    // exclusive product scan of `keep` across lanes
-    float incl = keep;
+    double run = 1.0;
+    float trans[C];
+    for (int l = 0; l < 64; ++l) {   // wave-uniform trip count; samples behind N carry keep = 1
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float up = __shfl_up(incl, off);
-        if (lane >= off) incl = incl * up;
+        for (int k = 0; k < C; ++k) {
+            if (lane == l) trans[k] = (float)run;
+            run = run * (double)__shfl(keep[k], l);
+        }
     }
-    float trans = __shfl_up(incl, 1);
-    if (lane == 0) trans = 1.0f;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < C; ++k) {
         const int i = lane * C + k;
         if (i < N) {
-            const float w = alpha[k] * trans;
-            trans = trans * (1.0f - alpha[k] + 1e-10f);
+            const float w = alpha[k] * trans[k];
             if (weights) weights[i] = w;
             if (rgb) {  // wave-uniform: the sigma-only coarse pass of a fused render has no colours
                 acc[0] = acc[0] + w * rgb[i * 3 + 0];

@@ -4,9 +4,24 @@
 //   styled: rendering.py:118-178 (render_style)   -- see mlp_style.hip
 #include "common.h"
 
-struct tgtc_net;
+#include "mlp_pack.h"
 
 namespace tgtc {
+struct FusedArgs {   // render_fused.hip
+    const double* rays_o;
+    const double* rays_d;
+    long long R;
+    int NC, NF;
+    float near_, far_;
+    const float* jitter;
+    const char* net_c;
+    const char* net_f;
+    float* rgb;
+    float* t;
+};
+int launch_fused_render(int prec_c, int prec_f, const FusedArgs& a, hipStream_t st);
+bool fused_render_supports(int prec_c, int prec_f, int n_coarse, int n_fine);
+
 int launch_composite(const float* rgb, const float* sigma, const float* ts, int64_t R, int N, float* rgb_exp,
                      float* t_exp, float* weights, hipStream_t st);
 int launch_sample_fine(const double* rays_o, const double* rays_d, const float* ts, const float* weights, int64_t R,
@@ -50,11 +65,31 @@ extern "C" size_t tgtc_render_workspace_bytes(int64_t R, int n_coarse, int n_fin
     return RenderWorkspace(nullptr, R, n_coarse, n_fine).total;
 }
 
+// The plain render.  Whenever the sample counts and precisions allow it (and the caller does not ask for the coarse
+// image) this is ONE launch of the fused ray kernel (render_fused.hip) and the workspace is not touched; otherwise
+// the chain of per-sample kernels below runs (tgtc_render_rays_plain_chain, always available).
 extern "C" int tgtc_render_rays_plain(const tgtc_net* coarse, const tgtc_net* fine, const double* rays_o,
                                       const double* rays_d, int64_t R, int n_coarse, int n_fine, float near_,
                                       float far_, const float* jitter, void* workspace, size_t workspace_bytes,
                                       float* rgb_fine, float* t_fine, float* rgb_coarse, float* t_coarse,
                                       void* stream) {
+    TGTC_REQUIRE(coarse && fine && R >= 0, "render_rays_plain: bad argument");
+    if (!rgb_coarse && !t_coarse && coarse->kind == 0 && fine->kind == 0 &&
+        fused_render_supports(coarse->precision, fine->precision, n_coarse, n_fine)) {
+        if (R == 0) return TGTC_OK;
+        TGTC_REQUIRE(rays_o && rays_d && rgb_fine && t_fine, "render_rays_plain: null pointer");
+        FusedArgs a{rays_o, rays_d, R, n_coarse, n_fine, near_, far_, jitter, coarse->dev, fine->dev, rgb_fine, t_fine};
+        return launch_fused_render(coarse->precision, fine->precision, a, as_stream(stream));
+    }
+    return tgtc_render_rays_plain_chain(coarse, fine, rays_o, rays_d, R, n_coarse, n_fine, near_, far_, jitter, workspace,
+                                        workspace_bytes, rgb_fine, t_fine, rgb_coarse, t_coarse, stream);
+}
+
+extern "C" int tgtc_render_rays_plain_chain(const tgtc_net* coarse, const tgtc_net* fine, const double* rays_o,
+                                            const double* rays_d, int64_t R, int n_coarse, int n_fine, float near_,
+                                            float far_, const float* jitter, void* workspace, size_t workspace_bytes,
+                                            float* rgb_fine, float* t_fine, float* rgb_coarse, float* t_coarse,
+                                            void* stream) {
     TGTC_REQUIRE(coarse && fine && R >= 0, "render_rays_plain: bad argument");
     // the reference dereferences None when N_samples_fine == 0; require it instead
     TGTC_REQUIRE(n_coarse >= 3 && n_fine >= 1, "render_rays_plain: need n_coarse >= 3 and n_fine >= 1 (got %d, %d)",

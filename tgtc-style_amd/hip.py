@@ -44,13 +44,13 @@ _SIGNATURES = {
     "tgtc_nerf_forward": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "tgtc_nerf_mlp_forward": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
     "tgtc_nerf_forward_rays": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p],
-    "tgtc_time_next_nerf_launch": [c_int, c_void_p, c_void_p],
-    "tgtc_debug_set_stamps": [c_void_p],
     "tgtc_composite": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "tgtc_sample_fine": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "tgtc_render_workspace_bytes": [c_int64, c_int, c_int],
     "tgtc_render_rays_plain": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float,
                                c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "tgtc_render_rays_plain_chain": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float,
+                                     c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "tgtc_image_epilogue": [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p],
     "tgtc_latents_forward": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_float, c_int,
                              c_void_p, c_void_p],

@@ -17,6 +17,20 @@ import torch.nn as nn
 from . import hip
 
 
+def _precision_of(args, role):
+    """`--precision` is one mode for every network or "coarse+fine" (precision belongs to each packed handle): the
+    coarse NeRF takes the first, the fine NeRF the second; the style MLPs are built for fp16x3 / fp16 and fall back
+    to fp16x3 where the fine NeRF runs fp16mx."""
+    p = getattr(args, 'precision', 'fp16x3')
+    first, _, second = p.partition('+')
+    second = second or first
+    if role == 'coarse':
+        return first
+    if role == 'fine':
+        return second
+    return second if second in ('fp16x3', 'fp16') else 'fp16x3'
+
+
 class Embedder(nn.Module):
     """reference models.py:24-60 (log-sampled bands, include_input, sin/cos)."""
 
@@ -119,7 +133,7 @@ class StyleNerf(nn.Module):
         self.net = MLP_style(D=depth, W=width, input_ch=self.embedder_coor.out_dim,
                              input_ch_viewdirs=self.embedder_dir.out_dim, skips=[4], use_viewdir=self.use_viewdir,
                              enable_style=enable_style)
-        self.net.precision = getattr(args, 'precision', 'fp16x3')
+        self.net.precision = _precision_of(args, mode)
         self.enable_style = enable_style
 
     def set_enable_style(self, enable_style=False):
@@ -169,7 +183,7 @@ class StyleMLP_before_concat(_Packed):
             dims.append(dim)
             dim = args.netwidth + args.vae_latent
         self.layers = nn.ModuleList([nn.Linear(d, args.netwidth) for d in dims])
-        self.precision = getattr(args, 'precision', 'fp16x3')
+        self.precision = _precision_of(args, 'style')
 
     def _pack(self):
         return hip.style_create(concat_state=self.state_dict(), precision=self.precision)
@@ -204,7 +218,7 @@ class StyleMLP_Wild_multilayers(_Packed):
             dim = args.netwidth + args.vae_latent
         self.layers = nn.ModuleList([nn.Linear(d, args.netwidth) for d in dims] +
                                     [nn.Linear(args.netwidth + args.vae_latent, 3)])
-        self.precision = getattr(args, 'precision', 'fp16x3')
+        self.precision = _precision_of(args, 'style')
 
     def _pack(self):
         return hip.style_create(style_state=self.state_dict(), precision=self.precision)

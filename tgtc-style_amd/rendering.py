@@ -22,9 +22,19 @@ class RayRenderer:
     style: optional `models.StylePair` for the stylised chain.
     """
 
-    def __init__(self, coarse, fine, style=None):
-        self.coarse, self.fine, self.style = coarse, fine, style
+    def __init__(self, coarse, fine, style=None, fused=True):
+        """fused=False forces the chain of per-sample kernels (tgtc_render_rays_plain_chain) where the library
+        would otherwise run the single persistent ray kernel; results agree to rounding (tests/test_fused_gpu.py)."""
+        self.coarse, self.fine, self.style, self.fused = coarse, fine, style, fused
         self._ws = None
+
+    def _fused_shape(self, nc, nf):
+        """Mirror of the library's rule (include/tgtc_hip.h, tgtc_render_rays_plain): when it renders with the single
+        fused kernel no workspace is needed."""
+        pc, pf = self.coarse.packed().precision, self.fine.packed().precision
+        pair = (pc, pf) in (("fp16x3", "fp16x3"), ("fp16x3", "fp16mx"), ("fp16", "fp16"))
+        step = 32 if pc == "fp16" else 16
+        return pair and nc >= 16 and nc % step == 0 and (nc + nf) % step == 0 and nc <= 192 and nc + nf <= 256
 
     def _workspace(self, R, nc, nf, device):
         need = hip.load().tgtc_render_workspace_bytes(R, nc, nf)
@@ -41,18 +51,21 @@ class RayRenderer:
         rays_o = rays_o.to(torch.float64).contiguous()
         rays_d = rays_d.to(torch.float64).contiguous()
         R, dev = rays_o.shape[0], rays_o.device
-        ws = self._workspace(R, n_coarse, n_fine, dev)
+        plain = self.style is None or z is None
+        one_kernel = plain and self.fused and not want_coarse and self._fused_shape(n_coarse, n_fine)
+        ws = None if one_kernel else self._workspace(R, n_coarse, n_fine, dev)
         rgb = torch.empty(R, 3, device=dev, dtype=torch.float32)
         t = torch.empty(R, device=dev, dtype=torch.float32)
         rgb_c = torch.empty(R, 3, device=dev, dtype=torch.float32) if want_coarse else None
         t_c = torch.empty(R, device=dev, dtype=torch.float32) if want_coarse else None
         if jitter is not None:
             jitter = jitter.to(torch.float32).contiguous()
-        if self.style is None or z is None:
-            hip.check(lib.tgtc_render_rays_plain(self.coarse.packed().handle, self.fine.packed().handle,
-                                                 hip.ptr(rays_o), hip.ptr(rays_d), R, n_coarse, n_fine, float(near),
-                                                 float(far), hip.ptr(jitter), hip.ptr(ws), ws.numel(), hip.ptr(rgb),
-                                                 hip.ptr(t), hip.ptr(rgb_c), hip.ptr(t_c), hip.stream()))
+        if plain:
+            fn = lib.tgtc_render_rays_plain if self.fused else lib.tgtc_render_rays_plain_chain
+            hip.check(fn(self.coarse.packed().handle, self.fine.packed().handle, hip.ptr(rays_o), hip.ptr(rays_d), R,
+                         n_coarse, n_fine, float(near), float(far), hip.ptr(jitter), hip.ptr(ws),
+                         0 if ws is None else ws.numel(), hip.ptr(rgb), hip.ptr(t), hip.ptr(rgb_c), hip.ptr(t_c),
+                         hip.stream()))
         else:
             z = z.to(torch.float32).contiguous()
             hip.check(lib.tgtc_render_rays_styled(self.coarse.packed().handle, self.fine.packed().handle,
@@ -88,6 +101,24 @@ def _require_fine(args):
     if not args.N_samples_fine > 0:
         raise ValueError("N_samples_fine must be > 0: the reference's render paths dereference None otherwise "
                          "(rendering.py:186; train_tgtcs.py:184)")
+
+
+# ---- multi-GPU hooks of the dataset duck type (train_tgtcs.ShardedScene; absent on reference-style datasets) --------
+# A rank either owns whole images (frames sharding: it renders image k iff k % world == rank and writes its files
+# itself) or a contiguous pixel range of EVERY image (rays sharding: the ranks' rows are all-gathered and rank 0
+# writes).  The drivers only need: the global number of the i-th image this rank completes, how many rays of an
+# image it renders, and how to assemble a finished image.
+def _image_id(ds, local_no):
+    return ds.global_image(local_no) if hasattr(ds, 'global_image') else local_no
+
+
+def _local_res(ds, res):
+    return ds.rays_per_image() if hasattr(ds, 'rays_per_image') else res
+
+
+def _assemble(ds, rgb, t):
+    """-> (rgb [h*w,3], t [h*w], this rank writes the files)"""
+    return ds.assemble(rgb, t) if hasattr(ds, 'assemble') else (rgb, t, True)
 
 
 def _write_depth_rgb(sv_path, rgb, t, h, w, rgb_name, depth_name, eps=1e-7, depth_channels=1):
@@ -169,8 +200,11 @@ def _styled_batch(b, args, ds, samp_func, model_forward, style_forward, concat_s
     rays_o, rays_d = b['rays_o'], b['rays_d']
     z = latents_model_1(style_ids=b['style_id'].long(), frame_ids=b['frame_id'].long(), type=args.dataset_type)
     if renderer is not None:
+        # stratified jitter (utils.py:518-524, perturb=True at rendering.py:118,280): the reference draws it per batch;
+        # a dataset may deliver it per ray instead, so that the image does not depend on batching or sharding
+        jitter = b['jitter'] if 'jitter' in b else torch.rand(rays_o.shape[0], args.N_samples, device=rays_o.device)
         out = renderer.render(rays_o, rays_d, args.N_samples, args.N_samples_fine, near=ds.near, far=ds.far,
-                              jitter=torch.rand(rays_o.shape[0], args.N_samples, device=rays_o.device), z=z)
+                              jitter=jitter, z=z)
         return out["rgb"], out["t"]
     R, L = rays_o.shape[0], z.shape[-1]
     zbar = torch.mean(z, dim=1, keepdim=True)                      # rendering.py:126
@@ -203,7 +237,7 @@ def render_style(model_forward, samp_func, style_forward, concat_style_forward, 
     ds = dataloader.dataset
     ds.mode = 'valid_style'
     frame_num, h, w = ds.cps_valid.shape[0], ds.h, ds.w
-    res = h * w
+    res = _local_res(ds, h * w)
     pend_rgb, pend_t, image_no = torch.zeros([0, 3], device=device), torch.zeros([0], device=device), 0
     for batch in dataloader:
         b = _to_device(batch, device)
@@ -212,11 +246,13 @@ def render_style(model_forward, samp_func, style_forward, concat_style_forward, 
         pend_rgb = torch.cat([pend_rgb, rgb_f.detach().float()], 0)      # stays on the device until a frame is complete
         pend_t = torch.cat([pend_t, t_f.detach().float()], 0)
         while pend_rgb.shape[0] >= res:
-            if sv_path is not None:
+            rgb_img, t_img, writer = _assemble(ds, pend_rgb[:res], pend_t[:res])
+            if sv_path is not None and writer:
                 # file numbering: images are consecutive (style, frame) pairs (rendering.py:209-218)
-                _write_depth_rgb(sv_path, pend_rgb[:res], pend_t[:res], h, w,
-                                 'style_%05d_fine_%05d.png' % (image_no // frame_num, image_no % frame_num),
-                                 'style_%05d_fine_depth_%05d.png' % (image_no // frame_num, image_no % frame_num))
+                gid = _image_id(ds, image_no)
+                _write_depth_rgb(sv_path, rgb_img, t_img, h, w,
+                                 'style_%05d_fine_%05d.png' % (gid // frame_num, gid % frame_num),
+                                 'style_%05d_fine_depth_%05d.png' % (gid // frame_num, gid % frame_num))
             image_no += 1
             pend_rgb, pend_t = pend_rgb[res:], pend_t[res:]
     return pend_rgb.cpu().numpy(), pend_t.cpu().numpy()
@@ -234,16 +270,19 @@ def render_train_style(samp_func, model_forward, style_forward, concat_style_for
     frame_num, h, w = dataset.frame_num, dataset.h, dataset.w
     dataset.mode = 'train_style'
     batch_size = args.chunk
-    while (h * w) % batch_size != 0:
+    local = _local_res(dataset, h * w)
+    while local % batch_size != 0:
         batch_size -= 1
-    iters_per_image = (h * w) // batch_size
+    iters_per_image = local // batch_size
     loader = dataset.batches(batch_size) if hasattr(dataset, 'batches') else torch.utils.data.DataLoader(
         dataset, shuffle=False, batch_size=batch_size, num_workers=getattr(args, 'num_workers', 0))
     it = img_count = 0
     rgbs, ts = [], []
     for batch in loader:
-        path = os.path.join(sv_path, 'style_%05d_fine_%05d.png' % (img_count // frame_num, img_count % frame_num))
-        exists = os.path.exists(path)
+        gid = _image_id(dataset, img_count)
+        path = os.path.join(sv_path, 'style_%05d_fine_%05d.png' % (gid // frame_num, gid % frame_num))
+        # (rays sharding: every rank must take the same decision, or the all-gather of a frame would hang)
+        exists = os.path.exists(path) and not hasattr(dataset, 'assemble')
         if not exists:
             b = _to_device(batch, device)
             rgb_f, t_f = _styled_batch(b, args, dataset, samp_func, model_forward, style_forward, concat_style_forward,
@@ -253,8 +292,10 @@ def render_train_style(samp_func, model_forward, style_forward, concat_style_for
         it += 1
         if it == iters_per_image:
             if not exists:
-                _write_depth_rgb(sv_path, torch.cat(rgbs, 0), torch.cat(ts, 0), h, w, os.path.basename(path),
-                                 os.path.basename(path).replace('_fine_', '_fine_depth_'), eps=0., depth_channels=3)
+                rgb_img, t_img, writer = _assemble(dataset, torch.cat(rgbs, 0), torch.cat(ts, 0))
+                if writer:
+                    _write_depth_rgb(sv_path, rgb_img, t_img, h, w, os.path.basename(path),
+                                     os.path.basename(path).replace('_fine_', '_fine_depth_'), eps=0., depth_channels=3)
             img_count += 1
             it, rgbs, ts = 0, [], []
     return img_count

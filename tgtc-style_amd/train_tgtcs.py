@@ -19,7 +19,49 @@ from . import config as cfg
 from . import models, rendering, synth, utils
 
 
-class SyntheticScene:
+class ShardedScene:
+    """Multi-GPU side of the dataset duck type (one process per GPU, torch.distributed).
+
+    shard = 'frames' (BASELINE config 5): rank r owns the images k with k % world == r, renders them whole and writes
+    their files itself -- no collective at all.  shard = 'rays' (config 4): every rank renders the contiguous pixel
+    range parallel.shard_range(h*w, rank, world) of EVERY image; a finished image is reassembled by one all-gather
+    of [rays, 4] rows (RCCL over xGMI with the nccl backend) and written by rank 0."""
+    rank, world, shard, dist = 0, 1, 'frames', None
+    jitter_samples, jitter_seed = 0, 0     # > 0: batches carry per-ray stratified jitter drawn from a per-IMAGE generator
+
+    def image_jitter(self, k):
+        """[h*w, N_samples] uniforms of image k: the same rows whatever the batch size, rank or sharding."""
+        g = torch.Generator(device=self.device)
+        g.manual_seed(self.jitter_seed + 1000003 * k)
+        return torch.rand(self.h * self.w, self.jitter_samples, generator=g, device=self.device)
+
+    def set_sharding(self, rank, world, shard, dist=None):
+        self.rank, self.world, self.shard, self.dist = rank, world, shard, dist
+
+    def _images(self, n_img):
+        return [k for k in range(n_img) if self.shard == 'rays' or k % self.world == self.rank]
+
+    def _pixels(self):
+        from . import parallel
+        return parallel.shard_range(self.h * self.w, self.rank, self.world) if self.shard == 'rays' else (0, self.h * self.w)
+
+    # hooks read by rendering.py
+    def global_image(self, local_no):
+        return local_no if self.shard == 'rays' else local_no * self.world + self.rank
+
+    def rays_per_image(self):
+        lo, hi = self._pixels()
+        return hi - lo
+
+    def assemble(self, rgb, t):
+        if self.world == 1 or self.shard != 'rays':
+            return rgb, t, True
+        from . import parallel
+        rows = parallel.gather_rows(torch.cat([rgb, t[:, None]], 1).contiguous(), self.h * self.w, self.rank, self.world, self.dist)
+        return rows[:, :3], rows[:, 3], self.rank == 0
+
+
+class SyntheticScene(ShardedScene):
     """Duck type of the reference datasets for the render drivers (dataset.py:361-470 attributes), with rays
     generated on the device per frame instead of stored float64 tables (dataset.py:412-433)."""
 
@@ -36,13 +78,19 @@ class SyntheticScene:
     def batches(self, batch_size):
         poses = self.cps if 'train' in self.mode else self.cps_valid
         n_img = len(poses) * (self.style_num if 'style' in self.mode else 1)
-        for k in range(n_img):
+        first, last = self._pixels()
+        for k in self._images(n_img):
             sid, fid = divmod(k, len(poses))
-            o, d = utils.gen_rays(self.h, self.w, self.f, poses[fid][:3, :4], device=self.device)
-            for lo in range(0, self.h * self.w, batch_size):
-                n = min(batch_size, self.h * self.w - lo)
-                yield {'rays_o': o[lo:lo + n], 'rays_d': d[lo:lo + n],
-                       'style_id': torch.full((n,), sid, dtype=torch.long), 'frame_id': torch.full((n,), fid, dtype=torch.long)}
+            o, d = utils.gen_rays(self.h, self.w, self.f, poses[fid][:3, :4], first_pixel=first, n=last - first,
+                                  device=self.device)
+            jit = self.image_jitter(k)[first:last] if self.jitter_samples and 'style' in self.mode else None
+            for lo in range(0, last - first, batch_size):
+                n = min(batch_size, last - first - lo)
+                batch = {'rays_o': o[lo:lo + n], 'rays_d': d[lo:lo + n],
+                         'style_id': torch.full((n,), sid, dtype=torch.long), 'frame_id': torch.full((n,), fid, dtype=torch.long)}
+                if jit is not None:
+                    batch['jitter'] = jit[lo:lo + n]
+                yield batch
 
 
 class LlffPoseScene(SyntheticScene):
@@ -81,10 +129,29 @@ def _newest(path, want, reject=()):
     return os.path.join(path, files[-1]) if files else None
 
 
+def _init_distributed():
+    """One process per GPU under torchrun (RANK / WORLD_SIZE / LOCAL_RANK); the process group comes up BEFORE the first
+    HIP call of the process.  TGTC_DIST_BACKEND=gloo lets several ranks share a GPU (functional rehearsals, tests)."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return 0, 1, 0, None
+    import torch.distributed as dist
+    backend = os.environ.get("TGTC_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+        local = local % max(torch.cuda.device_count(), 1)
+    return rank, world, local, dist
+
+
 def train(args):
+    rank, world, local, dist = _init_distributed()
     if not torch.cuda.is_available():
         raise SystemExit("train_tgtcs: no GPU visible; the HIP render path has no CPU fallback")
-    device = torch.device("cuda")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
     use_viewdir_str = '_UseViewDir_' if args.use_viewdir else ''
     sv_path = os.path.join(args.basedir, args.expname + '_' + args.nerf_type + '_' + args.act_type + use_viewdir_str +
                            'ImgFactor' + str(int(args.factor)))        # train_tgtcs.py:19-20
@@ -126,6 +193,12 @@ def train(args):
     else:
         raise SystemExit("train_tgtcs: no poses_bounds.npy in --datadir %s (the image side of the LLFF loader is not part "
                          "of this build, SURVEY section 8f); run with --synthetic for the seeded scene" % args.datadir)
+    dataset.jitter_samples = args.N_samples     # per-ray jitter: images independent of --batch_size / --chunk / sharding
+    if world > 1:
+        if args.render_valid or args.render_train:
+            raise SystemExit("train_tgtcs: the geometry pass (--render_valid / --render_train) writes one scene-wide "
+                             "geometry.npz and runs on one GPU; the stylised renders shard (--shard frames|rays)")
+        dataset.set_sharding(rank, world, args.shard, dist)
     latents = models.StyleLatents_variational(style_num=dataset.style_num, frame_num=dataset.frame_num,
                                               latent_dim=args.vae_latent).to(device)
     ck = None if args.no_reload else _newest(sv_path, ['tar', 'latent'], ['style'])       # train_tgtcs.py:139-146
@@ -167,11 +240,22 @@ def train(args):
                      "(the training loops of the reference are outside this build)")
 
 
+def _finish_distributed():
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
 def main(argv=None):
     args = cfg.parse_args(argv)
     if args.expname is None:
         raise SystemExit("train_tgtcs: --expname (or --config) is required")
-    return train(args)      # the reference wraps this in `while True` (train_tgtcs.py:596-597); once is enough
+    try:
+        return train(args)      # the reference wraps this in `while True` (train_tgtcs.py:596-597); once is enough
+    finally:
+        _finish_distributed()
 
 
 if __name__ == '__main__':

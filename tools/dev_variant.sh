@@ -6,5 +6,5 @@ set -e
 cd "$(dirname "$0")/../tgtc-style_amd/csrc"
 VAR="$1"; TAG="$2"; EXTRA="$3"
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on "-DTGTC_DEV_VARIANT=$VAR" $EXTRA -c mlp_nerf.hip -o /tmp/mlp_nerf_$TAG.o -Rpass-analysis=kernel-resource-usage
-hipcc -shared -fPIC --offload-arch=gfx950 -o libtgtc_dev_$TAG.so common.o raypath.o /tmp/mlp_nerf_$TAG.o mlp_nerf_mx.o render.o mlp_style.o mlp_style_fp16.o style2d.o
+hipcc -shared -fPIC --offload-arch=gfx950 -o libtgtc_dev_$TAG.so common.o raypath.o /tmp/mlp_nerf_$TAG.o mlp_nerf_mx.o render.o mlp_style.o mlp_style_fp16.o style2d.o render_fused.o
 echo built libtgtc_dev_$TAG.so
