@@ -19,7 +19,7 @@
 
 namespace tgtc {
 
-constexpr int BM = 128, BN = 128, BK = 32, LDK = 40;  // LDK: 32 halves + 8 pad -> 80-byte rows, conflict-free b128 reads
+constexpr int BK = 32, LDK = 40;  // LDK: 32 halves + 8 pad -> 80-byte rows, conflict-free b128 reads
 
 // ------------------------------------------------------------------------------------------------ row loaders
 // load4(ctx, k, v): v[j] = A(row, k + j), zero outside the matrix.  k is a multiple of 4.
@@ -127,9 +127,13 @@ __device__ __forceinline__ void put4(half_t* hi, half_t* lo, const float (&v)[4]
 
 // B operand: either rows of W [N][K] (nn.Linear / conv weights, BL = DenseRows) or, with B_KMAJOR, a
 // k-major matrix B[k][n] = p[k*ld + n] (the V operand of attention).
-template <class AL, bool SPLIT, bool B_KMAJOR>
+// WT = 16x16 accumulator tiles per wave and dimension: 4 -> 128x128 workgroup tiles, 2 -> 64x64 (chosen by launch_gemm
+// when 128x128 tiles would leave most of the 256 CUs idle: a [2500,512] projection is only 20x4 of them).
+template <class AL, bool SPLIT, bool B_KMAJOR, int WT>
 __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut out, int M, int N, int K) {
     constexpr int NP = SPLIT ? 2 : 1;
+    constexpr int BM = 32 * WT, BN = 32 * WT;
+    static_assert(!B_KMAJOR || WT == 4, "the k-major B loader is written for 128-wide tiles");
     __shared__ __attribute__((aligned(16))) half_t sA[NP][BM][LDK];
     __shared__ __attribute__((aligned(16))) half_t sB[NP][BN][LDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -143,20 +147,20 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
 
     // staging map: 4 rows x one k-quad per thread
     const int srow = tid >> 3, skq = (tid & 7) * 4;
-    typename AL::Ctx actx[4];
-    DenseRows::Ctx bctx[4];
+    typename AL::Ctx actx[WT];
+    DenseRows::Ctx bctx[WT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < WT; ++i) {
         actx[i] = al.prep(m0 + srow + 32 * i);
         if constexpr (!B_KMAJOR) bctx[i] = bl.prep(n0 + srow + 32 * i);
     }
     // k-major B: thread covers k = (tid>>5) + 8i, n-quad (tid&31)*4
     const int bk = tid >> 5, bnq = (tid & 31) * 4;
 
-    float ra[4][4], rb[4][4];
+    float ra[WT][4], rb[WT][4];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < WT; ++i) {
             al.load4(actx[i], k0 + skq, ra[i]);
             if constexpr (!B_KMAJOR) {
                 bl.load4(bctx[i], k0 + skq, rb[i]);
@@ -170,7 +174,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < WT; ++i) {
             put4<SPLIT>(&sA[0][srow + 32 * i][skq], &sA[NP - 1][srow + 32 * i][skq], ra[i]);
             if constexpr (!B_KMAJOR) {
                 put4<SPLIT>(&sB[0][srow + 32 * i][skq], &sB[NP - 1][srow + 32 * i][skq], rb[i]);
@@ -185,11 +189,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
         }
     };
 
-    float4v acc[4][4];
+    float4v acc[WT][WT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < WT; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
 
     const int KT = (K + BK - 1) / BK;
     fetch(0);
@@ -197,20 +201,20 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
         stash();
         __syncthreads();
         if (kt + 1 < KT) fetch((kt + 1) * BK);
-        half8 ah[4], al_[4], bh[4], bl_[4];
+        half8 ah[WT], al_[WT], bh[WT], bl_[WT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ah[i] = *reinterpret_cast<const half8*>(&sA[0][64 * wm + 16 * i + n16][8 * g]);
-            bh[i] = *reinterpret_cast<const half8*>(&sB[0][64 * wn + 16 * i + n16][8 * g]);
+        for (int i = 0; i < WT; ++i) {
+            ah[i] = *reinterpret_cast<const half8*>(&sA[0][16 * WT * wm + 16 * i + n16][8 * g]);
+            bh[i] = *reinterpret_cast<const half8*>(&sB[0][16 * WT * wn + 16 * i + n16][8 * g]);
             if constexpr (SPLIT) {
-                al_[i] = *reinterpret_cast<const half8*>(&sA[1][64 * wm + 16 * i + n16][8 * g]);
-                bl_[i] = *reinterpret_cast<const half8*>(&sB[1][64 * wn + 16 * i + n16][8 * g]);
+                al_[i] = *reinterpret_cast<const half8*>(&sA[1][16 * WT * wm + 16 * i + n16][8 * g]);
+                bl_[i] = *reinterpret_cast<const half8*>(&sB[1][16 * WT * wn + 16 * i + n16][8 * g]);
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < WT; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < WT; ++j) {
                 acc[i][j] = mfma16(ah[i], bh[j], acc[i][j]);
                 if constexpr (SPLIT) {
                     acc[i][j] = mfma16(al_[i], bh[j], acc[i][j]);
@@ -222,15 +226,15 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
 
     // epilogue: lane holds rows m = .. + 4g + r, column n = .. + (lane & 15)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + 64 * wn + 16 * j + n16;
+        for (int j = 0; j < WT; ++j) {
+            const int n = n0 + 16 * WT * wn + 16 * j + n16;
             if (n >= N) continue;
             const float b = out.bias ? out.bias[n] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 64 * wm + 16 * i + 4 * g + r;
+                const int m = m0 + 16 * WT * wm + 16 * i + 4 * g + r;
                 if (m >= M) continue;
                 const long long o = (long long)m * out.sm + (long long)n * out.sn;
                 float v = out.alpha * acc[i][j][r] + b;
@@ -239,6 +243,169 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
                 out.C[o] = v;
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+// nn.MultiheadAttention's softmax(q k^T / sqrt(64)) v for 8 heads of 64, never materialising the [8, L, S] scores
+// (transformer.py:167-263 through torch's MultiheadAttention; 2 500 x 2 500 tokens at 400x400).
+//
+// attn_prep_kernel splits the projected q / k / v once into the fp16 hi / lo operands the MFMAs take (q scaled by
+// 1/8, exact), v TRANSPOSED per feature ([512][S_pad]) and k / v zero-padded to a multiple of 64 keys.
+// attn_kernel: one workgroup = one head x 64 queries, four waves of 16 queries, key tiles of 64 through LDS.
+// Both products are evaluated transposed so that the QUERY sits on the MFMA lane:
+//   S^T[key, q] = K[key, d] . Q^T[d, q]          (A = K tile rows from LDS, B = Q^T fragments held in registers)
+//   O^T[d, q]  += V^T[d, key] . P^T[key, q]      (A = V^T tile rows from LDS, B = P^T)
+// The accumulator tile of S^T (rows = keys 4g+r, column = query lane&15) is, after exp and conversion, exactly the B
+// fragment of the second product (two 16-key tiles form one 32-deep k-step, CDNA guide "An accumulator tile as the
+// next MFMA's operand"), so P never crosses lanes or LDS; a query's running maximum and sum need two shuffles
+// (over the four lane groups) per key tile.  fp16x3: every product is hi*hi + lo*hi + hi*lo.
+constexpr int kAttnLd = 72;   // LDS row stride in halves (64 + 8 pad: conflict-free 16-byte reads)
+
+__global__ void __launch_bounds__(256) attn_prep_kernel(const float* __restrict__ q, long long ldq, int L,
+                                                        const float* __restrict__ k, long long ldk,
+                                                        const float* __restrict__ v, long long ldv, int S, int S_pad,
+                                                        half_t* __restrict__ qh, half_t* __restrict__ ql,
+                                                        half_t* __restrict__ kh, half_t* __restrict__ kl,
+                                                        half_t* __restrict__ vth, half_t* __restrict__ vtl) {
+    const long long nq = (long long)L * 512, nk = (long long)S_pad * 512;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    auto split = [](float x, half_t& h, half_t& l) {
+        h = (half_t)x;
+        l = (half_t)(x - (float)h);
+    };
+    if (i < nq) {
+        const long long r = i >> 9;
+        const int c = (int)(i & 511);
+        split(q[r * ldq + c] * 0.125f, qh[i], ql[i]);
+    } else if (i < nq + nk) {
+        const long long j = i - nq, r = j >> 9;
+        const int c = (int)(j & 511);
+        split(r < S ? k[r * ldk + c] : 0.0f, kh[j], kl[j]);
+    } else if (i < nq + 2 * nk) {
+        // v^T: thread index walks [feature][key] so the stores are coalesced
+        const long long j = i - nq - nk;
+        const int c = (int)(j / S_pad);
+        const long long r = j % S_pad;
+        split(r < S ? v[r * ldv + c] : 0.0f, vth[j], vtl[j]);
+    }
+}
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(256) attn_kernel(const half_t* __restrict__ qh, const half_t* __restrict__ ql,
+                                                   const half_t* __restrict__ kh, const half_t* __restrict__ kl,
+                                                   const half_t* __restrict__ vth, const half_t* __restrict__ vtl,
+                                                   int L, int S, int S_pad, float* __restrict__ out) {
+    constexpr int NP = SPLIT ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) half_t sK[NP][64][kAttnLd];
+    __shared__ __attribute__((aligned(16))) half_t sV[NP][64][kAttnLd];   // [d][key]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int head = blockIdx.y;
+    const int qi = blockIdx.x * 64 + wave * 16 + n;        // this lane's query
+    const bool qok = qi < L;
+
+    half8 Qh[2], Ql[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const long long o = (long long)(qok ? qi : 0) * 512 + head * 64 + 32 * ks + 8 * g;
+        Qh[ks] = qok ? *reinterpret_cast<const half8*>(qh + o) : half8{};
+        if constexpr (SPLIT) Ql[ks] = qok ? *reinterpret_cast<const half8*>(ql + o) : half8{};
+    }
+    float4v O[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) O[dt] = float4v{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, lsum = 0.0f;
+
+    const int srow = tid >> 2, sc0 = (tid & 3) * 16;    // staging: 64 rows x 64 halves = 256 threads x 2 half8
+    for (int key0 = 0; key0 < S; key0 += 64) {
+        __syncthreads();   // the previous tile is consumed
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int col = sc0 + 8 * i;
+            const long long ko = (long long)(key0 + srow) * 512 + head * 64 + col;
+            const long long vo = (long long)(head * 64 + srow) * S_pad + key0 + col;
+            *reinterpret_cast<half8*>(&sK[0][srow][col]) = *reinterpret_cast<const half8*>(kh + ko);
+            *reinterpret_cast<half8*>(&sV[0][srow][col]) = *reinterpret_cast<const half8*>(vth + vo);
+            if constexpr (SPLIT) {
+                *reinterpret_cast<half8*>(&sK[1][srow][col]) = *reinterpret_cast<const half8*>(kl + ko);
+                *reinterpret_cast<half8*>(&sV[1][srow][col]) = *reinterpret_cast<const half8*>(vtl + vo);
+            }
+        }
+        __syncthreads();
+
+        // S^T tiles: keys 16kt + 4g + r, query n
+        float4v sc[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            sc[kt] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const half8 ah = *reinterpret_cast<const half8*>(&sK[0][16 * kt + n][32 * ks + 8 * g]);
+                sc[kt] = mfma16(ah, Qh[ks], sc[kt]);
+                if constexpr (SPLIT) {
+                    const half8 al = *reinterpret_cast<const half8*>(&sK[1][16 * kt + n][32 * ks + 8 * g]);
+                    sc[kt] = mfma16(al, Qh[ks], sc[kt]);
+                    sc[kt] = mfma16(ah, Ql[ks], sc[kt]);
+                }
+            }
+        }
+        // online softmax for query n: this lane holds 16 of the tile's 64 keys, the other lane groups the rest
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (key0 + 16 * kt + 4 * g + r >= S) sc[kt][r] = -INFINITY;   // padding keys
+                tmax = fmaxf(tmax, sc[kt][r]);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m, tmax);          // finite: every tile holds at least one real key
+        const float alpha = expf(m - m_new);         // exp(-inf) = 0 on the first tile
+        m = m_new;
+        lsum *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) O[dt] = O[dt] * alpha;
+        half8 Ph[2], Pl[2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = expf(sc[kt][r] - m);
+                lsum += p;
+                const half_t h = (half_t)p;
+                Ph[kt >> 1][(kt & 1) * 4 + r] = h;
+                if constexpr (SPLIT) Pl[kt >> 1][(kt & 1) * 4 + r] = (half_t)(p - (float)h);
+            }
+        // O^T tiles: features 16dt + 4g + r, query n;  k-step ks = keys 32ks + {4g..4g+3, 16+4g..16+4g+3}
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                const half4 a0 = *reinterpret_cast<const half4*>(&sV[0][16 * dt + n][32 * ks + 4 * g]);
+                const half4 a1 = *reinterpret_cast<const half4*>(&sV[0][16 * dt + n][32 * ks + 16 + 4 * g]);
+                const half8 ah = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                O[dt] = mfma16(ah, Ph[ks], O[dt]);
+                if constexpr (SPLIT) {
+                    const half4 b0 = *reinterpret_cast<const half4*>(&sV[1][16 * dt + n][32 * ks + 4 * g]);
+                    const half4 b1 = *reinterpret_cast<const half4*>(&sV[1][16 * dt + n][32 * ks + 16 + 4 * g]);
+                    const half8 al = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    O[dt] = mfma16(al, Ph[ks], O[dt]);
+                    O[dt] = mfma16(ah, Pl[ks], O[dt]);
+                }
+            }
+    }
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    if (qok) {
+        const float inv = 1.0f / lsum;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float4 o4{O[dt][0] * inv, O[dt][1] * inv, O[dt][2] * inv, O[dt][3] * inv};
+            *reinterpret_cast<float4*>(out + (long long)qi * 512 + head * 64 + 16 * dt + 4 * g) = o4;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ small kernels
@@ -452,11 +619,20 @@ template <class AL, bool KM>
 static int launch_gemm(const tgtc_style2d* h, AL al, DenseRows bl, GemmOut out, int M, int N, int K, int batch,
                        hipStream_t st) {
     if (M <= 0 || N <= 0) return TGTC_OK;
-    dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, batch);
-    if (h->precision == TGTC_PREC_FP16)
-        gemm_kernel<AL, false, KM><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
-    else
-        gemm_kernel<AL, true, KM><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+    const long long big = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+    if (KM || big >= 256) {   // 128x128 tiles fill the chip (or the k-major loader, which only exists at that size)
+        dim3 grid((M + 127) / 128, (N + 127) / 128, batch);
+        if (h->precision == TGTC_PREC_FP16)
+            gemm_kernel<AL, false, KM, 4><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+        else
+            gemm_kernel<AL, true, KM, 4><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+    } else if constexpr (!KM) {
+        dim3 grid((M + 63) / 64, (N + 63) / 64, batch);
+        if (h->precision == TGTC_PREC_FP16)
+            gemm_kernel<AL, false, false, 2><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+        else
+            gemm_kernel<AL, true, false, 2><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+    }
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;
 }
@@ -495,26 +671,33 @@ static int mha(const tgtc_style2d* h, const std::string& p, const float* q_in, l
     const float* ow = need(h->tr, p + "out_proj.weight");
     const float* ob = need(h->tr, p + "out_proj.bias");
     if (!w || !b || !ow || !ob) return fail(TGTC_ERR_ARG, "style2d: missing attention parameters '%s*'", p.c_str());
+    const int S_pad = (S + 63) / 64 * 64;
     float* Q = ws.take((size_t)L * 512);
     float* Kp = ws.take((size_t)S * 512);
     float* V = ws.take((size_t)S * 512);
     float* O = ws.take((size_t)L * 512);
-    float* P = ws.take((size_t)8 * L * S);
+    // fp16 hi / lo operands of the attention kernel (two halves per float slot)
+    half_t* qh = reinterpret_cast<half_t*>(ws.take((size_t)L * 512));
+    half_t* ql = qh + (size_t)L * 512;
+    half_t* kh = reinterpret_cast<half_t*>(ws.take((size_t)S_pad * 512));
+    half_t* kl = kh + (size_t)S_pad * 512;
+    half_t* vth = reinterpret_cast<half_t*>(ws.take((size_t)S_pad * 512));
+    half_t* vtl = vth + (size_t)S_pad * 512;
     if (!ws.ok) return fail(TGTC_ERR_ARG, "style2d: workspace too small for attention (L=%d, S=%d)", L, S);
     TGTC_TRY(linear(h, q_in, ldq, L, 512, w, b, 512, Q, 512, nullptr, 0, st));
     TGTC_TRY(linear(h, k_in, ldk, S, 512, w + 512 * 512, b + 512, 512, Kp, 512, nullptr, 0, st));
     TGTC_TRY(linear(h, v_in, ldv, S, 512, w + 2 * 512 * 512, b + 1024, 512, V, 512, nullptr, 0, st));
-    {   // scores[h] = (q_h / sqrt(64)) k_h^T   (the 1/8 scale is exact in binary, so scaling the product == scaling q)
-        DenseRows al{Q, 512, 64, L, 64}, bl{Kp, 512, 64, S, 64};
-        GemmOut o{P, S, 1, (long long)L * S, nullptr, nullptr, 0.125f, 0};
-        TGTC_TRY((launch_gemm<DenseRows, false>(h, al, bl, o, L, S, 64, 8, st)));
-    }
-    softmax_rows_kernel<<<8 * L, 256, 0, st>>>(P, S);
-    TGTC_LAUNCH_CHECK();
-    {   // O[:, 64h:64h+64] = P_h V_h
-        DenseRows al{P, S, (long long)L * S, L, S}, bl{V, 512, 64, 64, S};
-        GemmOut o{O, 512, 1, 64, nullptr, nullptr, 1.0f, 0};
-        TGTC_TRY((launch_gemm<DenseRows, true>(h, al, bl, o, L, 64, S, 8, st)));
+    {
+        const long long total = (long long)L * 512 + 2LL * S_pad * 512;
+        attn_prep_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(Q, 512, L, Kp, 512, V, 512, S, S_pad, qh, ql, kh, kl,
+                                                                             vth, vtl);
+        TGTC_LAUNCH_CHECK();
+        const dim3 grid((L + 63) / 64, 8);
+        if (h->precision == TGTC_PREC_FP16)
+            attn_kernel<false><<<grid, 256, 0, st>>>(qh, ql, kh, kl, vth, vtl, L, S, S_pad, O);
+        else
+            attn_kernel<true><<<grid, 256, 0, st>>>(qh, ql, kh, kl, vth, vtl, L, S, S_pad, O);
+        TGTC_LAUNCH_CHECK();
     }
     return linear(h, O, 512, L, 512, ow, ob, 512, out, 512, nullptr, 0, st);
 }
@@ -595,7 +778,7 @@ static int decoder_layer(const tgtc_style2d* h, const std::string& p, const floa
 
 static size_t layer_ws_floats(size_t L, size_t S) {
     // generous upper bound for one encoder / decoder layer incl. attention scratch (256-byte rounding included)
-    return 1536 * S + 12 * 512 * (L + S) + 8 * L * S + 2048 * (L + S) + 64 * 64;
+    return 1536 * S + 16 * 512 * (L + S + 64) + 2048 * (L + S) + 64 * 64;
 }
 
 static int conv3x3(const tgtc_style2d* h, const float* w, const float* b, const float* in, int Hs, int Ws, int up,

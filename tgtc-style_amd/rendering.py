@@ -282,7 +282,7 @@ def render_train_style(samp_func, model_forward, style_forward, concat_style_for
         gid = _image_id(dataset, img_count)
         path = os.path.join(sv_path, 'style_%05d_fine_%05d.png' % (gid // frame_num, gid % frame_num))
         # (rays sharding: every rank must take the same decision, or the all-gather of a frame would hang)
-        exists = os.path.exists(path) and not hasattr(dataset, 'assemble')
+        exists = os.path.exists(path) and not (getattr(dataset, 'world', 1) > 1 and getattr(dataset, 'shard', '') == 'rays')
         if not exists:
             b = _to_device(batch, device)
             rgb_f, t_f = _styled_batch(b, args, dataset, samp_func, model_forward, style_forward, concat_style_forward,
