@@ -110,19 +110,27 @@ struct GemmOut {
     const float* res;                // same layout as C, or null
     float alpha;
     int relu;
+    long long bias_batch_stride = 0; // floats between the bias vectors of consecutive batches (blockIdx.z)
 };
 
+// four fp32 values -> fp16 hi (+ lo) halves in LDS.  The lo halves come straight out of v_fma_mixlo/mixhi_f16
+// (v * 1.0 - h in fp32, rounded once): two packed converts and four mixed FMAs instead of sixteen convert / subtract
+// instructions -- the staging of these GEMMs is VALU-bound, not memory-bound.
 template <bool SPLIT>
 __device__ __forceinline__ void put4(half_t* hi, half_t* lo, const float (&v)[4]) {
-    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-    half4 h, l;
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    unsigned h[2], l[2] = {0u, 0u};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        h[j] = (half_t)v[j];
-        l[j] = (half_t)(v[j] - (float)h[j]);
+    for (int p = 0; p < 2; ++p) {
+        h[p] = __builtin_bit_cast(unsigned, __builtin_convertvector((float2v{v[2 * p], v[2 * p + 1]}), half2v));
+        if constexpr (SPLIT) {
+            asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(l[p]) : "v"(v[2 * p]), "v"(h[p]));
+            asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l[p]) : "v"(v[2 * p + 1]), "v"(h[p]));
+        }
     }
-    *reinterpret_cast<half4*>(hi) = h;
-    if constexpr (SPLIT) *reinterpret_cast<half4*>(lo) = l;
+    *reinterpret_cast<uint2*>(hi) = uint2{h[0], h[1]};
+    if constexpr (SPLIT) *reinterpret_cast<uint2*>(lo) = uint2{l[0], l[1]};
 }
 
 // B operand: either rows of W [N][K] (nn.Linear / conv weights, BL = DenseRows) or, with B_KMAJOR, a
@@ -144,6 +152,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
     bl.p += (long long)blockIdx.z * bl.batch_stride;
     out.C += (long long)blockIdx.z * out.batch_stride;
     if (out.res) out.res += (long long)blockIdx.z * out.batch_stride;
+    if (out.bias) out.bias += (long long)blockIdx.z * out.bias_batch_stride;
 
     // staging map: 4 rows x one k-quad per thread
     const int srow = tid >> 3, skq = (tid & 7) * 4;
@@ -317,21 +326,36 @@ __global__ void __launch_bounds__(256) attn_kernel(const half_t* __restrict__ qh
     float m = -INFINITY, lsum = 0.0f;
 
     const int srow = tid >> 2, sc0 = (tid & 3) * 16;    // staging: 64 rows x 64 halves = 256 threads x 2 half8
-    for (int key0 = 0; key0 < S; key0 += 64) {
-        __syncthreads();   // the previous tile is consumed
+    // the NEXT tile travels global -> registers while the current one is multiplied (one LDS buffer, two barriers a tile)
+    half8 nk[NP][2], nv[NP][2];
+    auto fetch = [&](int key0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int col = sc0 + 8 * i;
             const long long ko = (long long)(key0 + srow) * 512 + head * 64 + col;
             const long long vo = (long long)(head * 64 + srow) * S_pad + key0 + col;
-            *reinterpret_cast<half8*>(&sK[0][srow][col]) = *reinterpret_cast<const half8*>(kh + ko);
-            *reinterpret_cast<half8*>(&sV[0][srow][col]) = *reinterpret_cast<const half8*>(vth + vo);
+            nk[0][i] = *reinterpret_cast<const half8*>(kh + ko);
+            nv[0][i] = *reinterpret_cast<const half8*>(vth + vo);
             if constexpr (SPLIT) {
-                *reinterpret_cast<half8*>(&sK[1][srow][col]) = *reinterpret_cast<const half8*>(kl + ko);
-                *reinterpret_cast<half8*>(&sV[1][srow][col]) = *reinterpret_cast<const half8*>(vtl + vo);
+                nk[1][i] = *reinterpret_cast<const half8*>(kl + ko);
+                nv[1][i] = *reinterpret_cast<const half8*>(vtl + vo);
+            }
+        }
+    };
+    fetch(0);
+    for (int key0 = 0; key0 < S; key0 += 64) {
+        __syncthreads();   // the previous tile is consumed
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int col = sc0 + 8 * i;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                *reinterpret_cast<half8*>(&sK[p][srow][col]) = nk[p][i];
+                *reinterpret_cast<half8*>(&sV[p][srow][col]) = nv[p][i];
             }
         }
         __syncthreads();
+        if (key0 + 64 < S) fetch(key0 + 64);
 
         // S^T tiles: keys 16kt + 4g + r, query n
         float4v sc[4];
@@ -684,12 +708,34 @@ static int mha(const tgtc_style2d* h, const std::string& p, const float* q_in, l
     half_t* vth = reinterpret_cast<half_t*>(ws.take((size_t)S_pad * 512));
     half_t* vtl = vth + (size_t)S_pad * 512;
     if (!ws.ok) return fail(TGTC_ERR_ARG, "style2d: workspace too small for attention (L=%d, S=%d)", L, S);
-    TGTC_TRY(linear(h, q_in, ldq, L, 512, w, b, 512, Q, 512, nullptr, 0, st));
-    TGTC_TRY(linear(h, k_in, ldk, S, 512, w + 512 * 512, b + 512, 512, Kp, 512, nullptr, 0, st));
-    TGTC_TRY(linear(h, v_in, ldv, S, 512, w + 2 * 512 * 512, b + 1024, 512, V, 512, nullptr, 0, st));
+    // in_proj: three [*,512] x [512,512] products.  Alone each is 20 x 4 tiles of 128 on 256 CUs; batch what can be:
+    long long ldK = 512, ldV = 512;
+    auto batched = [&](const float* a, long long lda, long long a_stride, int rows, int first, int count, float* y) {
+        DenseRows al{a, lda, a_stride, rows, 512}, bl{w + (size_t)first * 512 * 512, 512, 512 * 512, 512, 512};
+        GemmOut o{y, 512, 1, (long long)rows * 512, b + first * 512, nullptr, 1.0f, 0};
+        o.bias_batch_stride = 512;
+        return launch_gemm<DenseRows, false>(h, al, bl, o, rows, 512, 512, count, st);
+    };
+    const bool same_ld = ldq == ldk && ldk == ldv, step_qk = L == S && ldq == ldk;
+    if (L == S && same_ld && k_in - q_in == v_in - k_in && Kp == Q + (size_t)L * 512 && V == Kp + (size_t)S * 512) {
+        TGTC_TRY(batched(q_in, ldq, k_in - q_in, L, 0, 3, Q));                     // encoder without pos: q | k | v slices
+    } else if (k_in == v_in && ldk == ldv) {
+        TGTC_TRY(linear(h, q_in, ldq, L, 512, w, b, 512, Q, 512, nullptr, 0, st));  // decoder: k and v share the memory
+        float* KV = ws.take((size_t)S * 1024);
+        if (!ws.ok) return fail(TGTC_ERR_ARG, "style2d: workspace too small for attention (L=%d, S=%d)", L, S);
+        TGTC_TRY(linear(h, k_in, ldk, S, 512, w + 512 * 512, b + 512, 1024, KV, 1024, nullptr, 0, st));
+        Kp = KV, V = KV + 512, ldK = ldV = 1024;
+    } else if (step_qk && Kp == Q + (size_t)L * 512) {
+        TGTC_TRY(batched(q_in, ldq, k_in - q_in, L, 0, 2, Q));                     // encoder with pos: q | k slices, v = src
+        TGTC_TRY(linear(h, v_in, ldv, S, 512, w + 2 * 512 * 512, b + 1024, 512, V, 512, nullptr, 0, st));
+    } else {
+        TGTC_TRY(linear(h, q_in, ldq, L, 512, w, b, 512, Q, 512, nullptr, 0, st));
+        TGTC_TRY(linear(h, k_in, ldk, S, 512, w + 512 * 512, b + 512, 512, Kp, 512, nullptr, 0, st));
+        TGTC_TRY(linear(h, v_in, ldv, S, 512, w + 2 * 512 * 512, b + 1024, 512, V, 512, nullptr, 0, st));
+    }
     {
         const long long total = (long long)L * 512 + 2LL * S_pad * 512;
-        attn_prep_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(Q, 512, L, Kp, 512, V, 512, S, S_pad, qh, ql, kh, kl,
+        attn_prep_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(Q, 512, L, Kp, ldK, V, ldV, S, S_pad, qh, ql, kh, kl,
                                                                              vth, vtl);
         TGTC_LAUNCH_CHECK();
         const dim3 grid((L + 63) / 64, 8);
