@@ -99,6 +99,17 @@ int tgtc_nerf_forward_rays(const tgtc_net* net, const double* rays_o, const doub
 int tgtc_composite(const float* rgb, const float* sigma, const float* ts, int64_t R, int N,
                    float* rgb_exp, float* t_exp, float* weights, void* stream);
 
+/* Training-side forms of a6 (train_tgtcs.py:218-309 differentiates through alpha_composition):
+ * composite_train: sigma + noise in front of the ReLUs (noise float [R,N] = randn * sigma_noise_std drawn by the caller,
+ *   utils.py:371-376, or NULL) and the optional white background (utils.py:381-384).
+ * composite_backward: dL/d rgb [R,N,3] and dL/d sigma [R,N] from dL/d rgb_exp [R,3], dL/d t_exp [R], dL/d weights [R,N]
+ *   (any of the three may be NULL = zero); either output may be NULL. */
+int tgtc_composite_train(const float* rgb, const float* sigma, const float* ts, const float* noise, int white_bkgd,
+                         int64_t R, int N, float* rgb_exp, float* t_exp, float* weights, void* stream);
+int tgtc_composite_backward(const float* rgb, const float* sigma, const float* ts, const float* noise, int white_bkgd,
+                            int64_t R, int N, const float* grad_rgb_exp, const float* grad_t_exp,
+                            const float* grad_weights, float* grad_rgb, float* grad_sigma, void* stream);
+
 /* ------------------------------------------------------------------ a7: fine sampling
  * utils.py:573-580 sampling_pts_fine_torch -> utils.py:583-609 sample_pdf(det=True), then the sorted merge.
  * ts [R,N], weights [R,N] -> ts_out [R,N+n_fine] ascending; pts_out [R,N+n_fine,3] double or NULL. */

@@ -119,7 +119,8 @@ __global__ void __launch_bounds__(256) posenc_kernel(const T* __restrict__ x, lo
 template <int C>
 __device__ __forceinline__ void composite_wave(const float* __restrict__ rgb, const float* __restrict__ sigma,
                                                const float* __restrict__ ts, int N, float* rgb_exp, float* t_exp,
-                                               float* weights) {
+                                               float* weights, const float* __restrict__ noise = nullptr,
+                                               int white_bkgd = 0) {
     const int lane = threadIdx.x & 63;
     float alpha[C], tv[C], keep[C];
 #pragma unroll
@@ -129,7 +130,8 @@ __device__ __forceinline__ void composite_wave(const float* __restrict__ rgb, co
         if (i < N) {
             const float t0 = ts[i];
             const float delta = (i + 1 < N) ? ts[i + 1] - t0 : 1e10f;       // utils.py:367-369
-            const float dens = fmaxf(fmaxf(sigma[i], 0.0f), 0.0f);          // relu(relu(.)) :365,:376
+            const float raw = noise ? sigma[i] + noise[i] : sigma[i];      // training-time regulariser, :371-376
+            const float dens = fmaxf(fmaxf(raw, 0.0f), 0.0f);               // relu(relu(.)) :365,:376
             alpha[k] = 1.0f - expf(-dens * delta);
             tv[k] = t0;
             keep[k] = 1.0f - alpha[k] + 1e-10f;                             // :378
@@ -145,11 +147,13 @@ __device__ __forceinline__ void composite_wave(const float* __restrict__ rgb, co
         }
     }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float wsum = 0.0f;
 #pragma unroll
     for (int k = 0; k < C; ++k) {
         const int i = lane * C + k;
         if (i < N) {
             const float w = alpha[k] * trans[k];
+            wsum = wsum + w;
             if (weights) weights[i] = w;
             if (rgb) {  // wave-uniform: the sigma-only coarse pass of a fused render has no colours
                 acc[0] = acc[0] + w * rgb[i * 3 + 0];
@@ -164,22 +168,117 @@ __device__ __forceinline__ void composite_wave(const float* __restrict__ rgb, co
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = acc[j] + __shfl_xor(acc[j], off);
     }
+    if (white_bkgd) {                                                       // rgb + (1 - acc_map), :381-384
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) wsum = wsum + __shfl_xor(wsum, off);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = acc[j] + (1.0f - wsum);
+    }
     if (lane == 0) {
         if (rgb_exp) rgb_exp[0] = acc[0], rgb_exp[1] = acc[1], rgb_exp[2] = acc[2];
         if (t_exp) t_exp[0] = acc[3];
     }
 }
 
+// Backward of alpha_composition (the training loops of the reference differentiate through it, train_tgtcs.py:218-309):
+// given dL/d rgb_exp [3], dL/d t_exp, dL/d weights [N] of one ray, produce dL/d rgb [N,3] and dL/d sigma [N].
+//   w_i = a_i T_i,  T_i = prod_{j<i} k_j,  k_j = 1 - a_j + 1e-10,  a_i = 1 - exp(-s_i d_i),  s_i = relu(relu(sigma_i + noise_i))
+//   G_i = g_rgb . c_i + g_t t_i + g_w_i                      (dL/dw_i)
+//   dL/da_i = G_i T_i - (sum_{m>i} G_m w_m) / k_i            (every later T_m carries the factor k_i)
+//   dL/dsigma_i = dL/da_i * d_i (1 - a_i) * [sigma_i + noise_i > 0]
+// One wavefront per ray, lane l owns samples [l*C, l*C+C); the suffix sum is a reverse wave scan.
+template <int C>
+__device__ __forceinline__ void composite_backward_wave(const float* __restrict__ rgb, const float* __restrict__ sigma,
+                                                        const float* __restrict__ ts, const float* __restrict__ noise,
+                                                        int N, int white_bkgd, const float* __restrict__ g_rgb,
+                                                        const float* __restrict__ g_t, const float* __restrict__ g_w,
+                                                        float* __restrict__ d_rgb, float* __restrict__ d_sigma) {
+    const int lane = threadIdx.x & 63;
+    float alpha[C], tv[C], keep[C], delta[C], live[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        const int i = lane * C + k;
+        alpha[k] = 0.0f, tv[k] = 0.0f, keep[k] = 1.0f, delta[k] = 0.0f, live[k] = 0.0f;
+        if (i < N) {
+            const float t0 = ts[i];
+            delta[k] = (i + 1 < N) ? ts[i + 1] - t0 : 1e10f;
+            const float raw = noise ? sigma[i] + noise[i] : sigma[i];
+            live[k] = raw > 0.0f ? 1.0f : 0.0f;
+            alpha[k] = 1.0f - expf(-fmaxf(raw, 0.0f) * delta[k]);
+            tv[k] = t0;
+            keep[k] = 1.0f - alpha[k] + 1e-10f;
+        }
+    }
+    double run = 1.0;
+    float trans[C];
+    for (int l = 0; l < 64; ++l) {
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            if (lane == l) trans[k] = (float)run;
+            run = run * (double)__shfl(keep[k], l);
+        }
+    }
+    const float gr = g_rgb ? g_rgb[0] : 0.0f, gg = g_rgb ? g_rgb[1] : 0.0f, gb = g_rgb ? g_rgb[2] : 0.0f;
+    const float gt = g_t ? g_t[0] : 0.0f;
+    // with a white background rgb_exp also carries -(sum w) in every channel: dL/dw_i gets -(gr + gg + gb)
+    const float gwhite = white_bkgd ? -(gr + gg + gb) : 0.0f;
+    float G[C], Gw[C], part = 0.0f;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        const int i = lane * C + k;
+        G[k] = Gw[k] = 0.0f;
+        if (i < N) {
+            const float w = alpha[k] * trans[k];
+            G[k] = gr * rgb[i * 3 + 0] + gg * rgb[i * 3 + 1] + gb * rgb[i * 3 + 2] + gt * tv[k] + (g_w ? g_w[i] : 0.0f) + gwhite;
+            Gw[k] = G[k] * w;
+            part += Gw[k];
+            if (d_rgb) d_rgb[i * 3 + 0] = w * gr, d_rgb[i * 3 + 1] = w * gg, d_rgb[i * 3 + 2] = w * gb;
+        }
+    }
+    // suffix sums: total of the lanes behind this one, then inside the run
+    float incl = part;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float dn = __shfl_down(incl, off);
+        if (lane + off < 64) incl = incl + dn;
+    }
+    float suffix = incl - part;   // sum over lanes > this lane
+#pragma unroll
+    for (int k = C - 1; k >= 0; --k) {
+        const int i = lane * C + k;
+        if (i < N && d_sigma) {
+            const float d_alpha = G[k] * trans[k] - suffix / keep[k];
+            d_sigma[i] = d_alpha * delta[k] * (1.0f - alpha[k]) * live[k];
+        }
+        suffix += Gw[k];
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) composite_backward_kernel(const float* __restrict__ rgb, const float* __restrict__ sigma,
+                                                                 const float* __restrict__ ts, const float* __restrict__ noise,
+                                                                 long long R, int N, int white_bkgd,
+                                                                 const float* __restrict__ g_rgb, const float* __restrict__ g_t,
+                                                                 const float* __restrict__ g_w, float* __restrict__ d_rgb,
+                                                                 float* __restrict__ d_sigma) {
+    const long long r = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (r >= R) return;  // wave-uniform
+    composite_backward_wave<C>(rgb + r * N * 3, sigma + r * N, ts + r * N, noise ? noise + r * N : nullptr, N, white_bkgd,
+                               g_rgb ? g_rgb + r * 3 : nullptr, g_t ? g_t + r : nullptr, g_w ? g_w + r * N : nullptr,
+                               d_rgb ? d_rgb + r * N * 3 : nullptr, d_sigma ? d_sigma + r * N : nullptr);
+}
+
 template <int C>
 __global__ void __launch_bounds__(256) composite_kernel(const float* __restrict__ rgb, const float* __restrict__ sigma,
                                                         const float* __restrict__ ts, long long R, int N,
                                                         float* __restrict__ rgb_exp, float* __restrict__ t_exp,
-                                                        float* __restrict__ weights) {
+                                                        float* __restrict__ weights, const float* __restrict__ noise,
+                                                        int white_bkgd) {
     const long long r = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     if (r >= R) return;  // wave-uniform
     composite_wave<C>(rgb ? rgb + r * N * 3 : nullptr, sigma + r * N, ts + r * N, N,
                       rgb_exp ? rgb_exp + r * 3 : nullptr, t_exp ? t_exp + r : nullptr,
-                      weights ? weights + r * N : nullptr);
+                      weights ? weights + r * N : nullptr, noise ? noise + r * N : nullptr, white_bkgd);
 }
 
 // ------------------------------------------------------------------------------------ fine sampling
@@ -347,19 +446,45 @@ extern "C" int tgtc_posenc(const void* x, int x_is_f64, int64_t M, int L, float*
 }
 
 namespace tgtc {
-int launch_composite(const float* rgb, const float* sigma, const float* ts, int64_t R, int N, float* rgb_exp,
-                     float* t_exp, float* weights, hipStream_t st) {
+int launch_composite_ex(const float* rgb, const float* sigma, const float* ts, int64_t R, int N, float* rgb_exp,
+                        float* t_exp, float* weights, hipStream_t st, const float* noise, int white_bkgd) {
     const unsigned nb = blocks_for(R, 4);
     const int C = (N + 63) / 64;
+#define TGTC_COMPOSITE(CC) composite_kernel<CC><<<nb, 256, 0, st>>>(rgb, sigma, ts, R, N, rgb_exp, t_exp, weights, noise, white_bkgd)
     switch (C) {
-        case 1: composite_kernel<1><<<nb, 256, 0, st>>>(rgb, sigma, ts, R, N, rgb_exp, t_exp, weights); break;
-        case 2: composite_kernel<2><<<nb, 256, 0, st>>>(rgb, sigma, ts, R, N, rgb_exp, t_exp, weights); break;
-        case 3: composite_kernel<3><<<nb, 256, 0, st>>>(rgb, sigma, ts, R, N, rgb_exp, t_exp, weights); break;
-        case 4: composite_kernel<4><<<nb, 256, 0, st>>>(rgb, sigma, ts, R, N, rgb_exp, t_exp, weights); break;
-        case 5: case 6: case 7: case 8:
-            composite_kernel<8><<<nb, 256, 0, st>>>(rgb, sigma, ts, R, N, rgb_exp, t_exp, weights); break;
+        case 1: TGTC_COMPOSITE(1); break;
+        case 2: TGTC_COMPOSITE(2); break;
+        case 3: TGTC_COMPOSITE(3); break;
+        case 4: TGTC_COMPOSITE(4); break;
+        case 5: case 6: case 7: case 8: TGTC_COMPOSITE(8); break;
         default: return fail(TGTC_ERR_UNSUPPORTED, "composite: N=%d samples per ray exceeds 512", N);
     }
+#undef TGTC_COMPOSITE
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
+}
+
+int launch_composite(const float* rgb, const float* sigma, const float* ts, int64_t R, int N, float* rgb_exp,
+                     float* t_exp, float* weights, hipStream_t st) {
+    return launch_composite_ex(rgb, sigma, ts, R, N, rgb_exp, t_exp, weights, st, nullptr, 0);
+}
+
+int launch_composite_backward(const float* rgb, const float* sigma, const float* ts, const float* noise, int64_t R, int N,
+                              int white_bkgd, const float* g_rgb, const float* g_t, const float* g_w, float* d_rgb,
+                              float* d_sigma, hipStream_t st) {
+    const unsigned nb = blocks_for(R, 4);
+    const int C = (N + 63) / 64;
+#define TGTC_COMPOSITE_BWD(CC) \
+    composite_backward_kernel<CC><<<nb, 256, 0, st>>>(rgb, sigma, ts, noise, R, N, white_bkgd, g_rgb, g_t, g_w, d_rgb, d_sigma)
+    switch (C) {
+        case 1: TGTC_COMPOSITE_BWD(1); break;
+        case 2: TGTC_COMPOSITE_BWD(2); break;
+        case 3: TGTC_COMPOSITE_BWD(3); break;
+        case 4: TGTC_COMPOSITE_BWD(4); break;
+        case 5: case 6: case 7: case 8: TGTC_COMPOSITE_BWD(8); break;
+        default: return fail(TGTC_ERR_UNSUPPORTED, "composite_backward: N=%d samples per ray exceeds 512", N);
+    }
+#undef TGTC_COMPOSITE_BWD
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;
 }
@@ -381,6 +506,26 @@ extern "C" int tgtc_composite(const float* rgb, const float* sigma, const float*
     if (R == 0) return TGTC_OK;
     TGTC_REQUIRE(rgb && sigma && ts && rgb_exp && t_exp, "composite: null pointer");
     return launch_composite(rgb, sigma, ts, R, N, rgb_exp, t_exp, weights, as_stream(stream));
+}
+
+extern "C" int tgtc_composite_train(const float* rgb, const float* sigma, const float* ts, const float* noise,
+                                    int white_bkgd, int64_t R, int N, float* rgb_exp, float* t_exp, float* weights,
+                                    void* stream) {
+    TGTC_REQUIRE(R >= 0 && N >= 1, "composite_train: bad argument");
+    if (R == 0) return TGTC_OK;
+    TGTC_REQUIRE(rgb && sigma && ts && rgb_exp && t_exp, "composite_train: null pointer");
+    return launch_composite_ex(rgb, sigma, ts, R, N, rgb_exp, t_exp, weights, as_stream(stream), noise, white_bkgd);
+}
+
+extern "C" int tgtc_composite_backward(const float* rgb, const float* sigma, const float* ts, const float* noise,
+                                       int white_bkgd, int64_t R, int N, const float* grad_rgb_exp,
+                                       const float* grad_t_exp, const float* grad_weights, float* grad_rgb,
+                                       float* grad_sigma, void* stream) {
+    TGTC_REQUIRE(R >= 0 && N >= 1, "composite_backward: bad argument");
+    if (R == 0) return TGTC_OK;
+    TGTC_REQUIRE(rgb && sigma && ts && (grad_rgb || grad_sigma), "composite_backward: null pointer");
+    return launch_composite_backward(rgb, sigma, ts, noise, R, N, white_bkgd, grad_rgb_exp, grad_t_exp, grad_weights, grad_rgb,
+                                     grad_sigma, as_stream(stream));
 }
 
 extern "C" int tgtc_sample_fine(const double* rays_o, const double* rays_d, const float* ts, const float* weights,

@@ -149,6 +149,10 @@ __global__ void __launch_bounds__(512, 2) fused_render_kernel(FusedArgs a) {
     // can hoist out of that loop stay live across the passes and are spilled (see fused_pass)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef TGTC_FUSED_PRIO
+    // experiment (CDNA guide T5, static form): the younger half of an 8-wave workgroup loses VALU arbitration on every segment
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     auto fresh_lane = [&] {
         int l = lane;
         asm volatile("" : "+v"(l));

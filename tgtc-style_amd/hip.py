@@ -45,6 +45,9 @@ _SIGNATURES = {
     "tgtc_nerf_mlp_forward": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
     "tgtc_nerf_forward_rays": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p],
     "tgtc_composite": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "tgtc_composite_train": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "tgtc_composite_backward": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p],
     "tgtc_sample_fine": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "tgtc_render_workspace_bytes": [c_int64, c_int, c_int],
     "tgtc_render_rays_plain": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float,

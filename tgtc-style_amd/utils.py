@@ -56,23 +56,58 @@ def sampling_pts_fine_torch(rays_o, rays_d, ts, weights, N_samples_fine=64):
     return pts, tv
 
 
-def alpha_composition(pts_rgb, pts_sigma, t_values, sigma_noise_std=0., white_bkgd=False):
-    """reference utils.py:354-386.  Returns (rgb_exp [R,3], t_exp [R], weights [R,N])."""
+class _Composite(torch.autograd.Function):
+    """alpha_composition as a differentiable op on the HIP kernels: forward tgtc_composite_train, backward
+    tgtc_composite_backward (gradients w.r.t. rgb and sigma; the depths and the injected noise carry none, as in the
+    reference, where they come from the sampler and from torch.randn)."""
+
+    @staticmethod
+    def forward(ctx, rgb, sigma, ts, noise, white_bkgd):
+        lib = hip.load()
+        R, N = sigma.shape
+        rgb_exp = torch.empty(R, 3, device=rgb.device, dtype=torch.float32)
+        t_exp = torch.empty(R, device=rgb.device, dtype=torch.float32)
+        w = torch.empty(R, N, device=rgb.device, dtype=torch.float32)
+        hip.check(lib.tgtc_composite_train(hip.ptr(rgb), hip.ptr(sigma), hip.ptr(ts), hip.ptr(noise), int(white_bkgd), R, N,
+                                           hip.ptr(rgb_exp), hip.ptr(t_exp), hip.ptr(w), hip.stream()))
+        ctx.save_for_backward(rgb, sigma, ts, noise)
+        ctx.white_bkgd = int(white_bkgd)
+        return rgb_exp, t_exp, w
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_t, g_w):
+        lib = hip.load()
+        rgb, sigma, ts, noise = ctx.saved_tensors
+        R, N = sigma.shape
+        d_rgb = torch.empty_like(rgb) if ctx.needs_input_grad[0] else None
+        d_sigma = torch.empty_like(sigma) if ctx.needs_input_grad[1] else None
+        c = lambda g: None if g is None else g.to(torch.float32).contiguous()
+        hip.check(lib.tgtc_composite_backward(hip.ptr(rgb), hip.ptr(sigma), hip.ptr(ts), hip.ptr(noise), ctx.white_bkgd, R, N,
+                                              hip.ptr(c(g_rgb)), hip.ptr(c(g_t)), hip.ptr(c(g_w)), hip.ptr(d_rgb),
+                                              hip.ptr(d_sigma), hip.stream()))
+        return d_rgb, d_sigma, None, None, None
+
+
+def alpha_composition(pts_rgb, pts_sigma, t_values, sigma_noise_std=0., white_bkgd=False, noise=None):
+    """reference utils.py:354-386.  Returns (rgb_exp [R,3], t_exp [R], weights [R,N]).  `noise` ([R,N], optional) is the
+    density regulariser already drawn (the reference draws randn * sigma_noise_std inside, :371-374); differentiable
+    w.r.t. pts_rgb and pts_sigma when they require grad (the reference's training loops, train_tgtcs.py:218-309)."""
     hip.require_gpu(pts_rgb, pts_sigma, t_values)
-    lib = hip.load()
-    if sigma_noise_std > 0:
-        # training-time regulariser (utils.py:372-374); the render paths always pass 0
-        pts_sigma = pts_sigma + torch.randn_like(pts_sigma) * sigma_noise_std
     rgb, sigma, ts = _f32(pts_rgb), _f32(pts_sigma), _f32(t_values)
-    R, N = sigma.shape
-    rgb_exp = torch.empty(R, 3, device=rgb.device, dtype=torch.float32)
-    t_exp = torch.empty(R, device=rgb.device, dtype=torch.float32)
-    w = torch.empty(R, N, device=rgb.device, dtype=torch.float32)
-    hip.check(lib.tgtc_composite(hip.ptr(rgb), hip.ptr(sigma), hip.ptr(ts), R, N, hip.ptr(rgb_exp), hip.ptr(t_exp),
-                                 hip.ptr(w), hip.stream()))
-    if white_bkgd:
-        rgb_exp = rgb_exp + (1. - w.sum(-1, keepdim=True))   # utils.py:383-384
-    return rgb_exp, t_exp, w
+    if noise is None and sigma_noise_std > 0:
+        noise = torch.randn(sigma.shape, device=sigma.device) * sigma_noise_std
+    if noise is not None:
+        noise = _f32(noise)
+    if noise is None and not white_bkgd and not (rgb.requires_grad or sigma.requires_grad):
+        lib = hip.load()
+        R, N = sigma.shape
+        rgb_exp = torch.empty(R, 3, device=rgb.device, dtype=torch.float32)
+        t_exp = torch.empty(R, device=rgb.device, dtype=torch.float32)
+        w = torch.empty(R, N, device=rgb.device, dtype=torch.float32)
+        hip.check(lib.tgtc_composite(hip.ptr(rgb), hip.ptr(sigma), hip.ptr(ts), R, N, hip.ptr(rgb_exp), hip.ptr(t_exp),
+                                     hip.ptr(w), hip.stream()))
+        return rgb_exp, t_exp, w
+    return _Composite.apply(rgb, sigma, ts, noise, bool(white_bkgd))
 
 
 def batchify(fn, chunk=1024 * 32):
