@@ -302,13 +302,13 @@ struct WeightStream {
     }
     // Pin the window's instruction mix: after every MFMA one pending ds_read (if any) and up to two VALU
     // instructions -- what fits into the ~8 spare issue cycles of a 16x16x32 MFMA -- then fence the window.
-    template <int F, int N_MFMA, int EXTRA_READS>
+    template <int F, int N_MFMA, int EXTRA_READS, int N_VALU = 2>
     __device__ __forceinline__ void close_window() const {
         constexpr int NR = reads_in_window(F) + EXTRA_READS;
         static_for<N_MFMA>([&](auto i_) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
             if constexpr (decltype(i_)::value < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // VALU
+            __builtin_amdgcn_sched_group_barrier(0x002, N_VALU, 0);  // VALU
         });
         __builtin_amdgcn_sched_barrier(0);
     }

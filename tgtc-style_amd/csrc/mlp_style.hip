@@ -71,6 +71,10 @@ __device__ __forceinline__ char* launder(char* p) {
 template <class C>
 __device__ __forceinline__ void stash_store(char* lane_slab, int ks, int c, half8 h, half8 l) {
     constexpr int P = C::SPLIT ? 2 : 1;
+    if constexpr (kAbl & 16) {   // timing ablation: no slab traffic (the values are consumed, results are garbage)
+        asm volatile("" ::"v"(h), "v"(l));
+        return;
+    }
     half8* p = reinterpret_cast<half8*>(launder(lane_slab)) + (size_t)((ks * C::NCT + c) * P) * (C::NWAVES * 64);
     p[0] = h;
     if constexpr (C::SPLIT) p[C::NWAVES * 64] = l;
@@ -78,6 +82,13 @@ __device__ __forceinline__ void stash_store(char* lane_slab, int ks, int c, half
 template <class C>
 __device__ __forceinline__ void stash_load(char* lane_slab, half8 (&Ah)[8][C::NCT], half8 (&Al)[8][C::NCT]) {
     constexpr int P = C::SPLIT ? 2 : 1;
+    if constexpr (kAbl & 16) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int c = 0; c < C::NCT; ++c) asm volatile("" : "=v"(Ah[ks][c]), "=v"(Al[ks][c]));
+        return;
+    }
     const half8* base = reinterpret_cast<const half8*>(launder(lane_slab));
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
