@@ -3,6 +3,6 @@
 # chain of per-sample kernels (tools/time_fused.py "chain" rows; TGTC_NERF_NARROW=1 forces the 16x16x32 kernels)
 python -m pytest tests/test_hip_nerf.py -x -q -m gpu -k "wide" 2>&1 | tail -15
 for i in 1 2; do
-  python tools/time_fused.py fp16x3 2>/dev/null | grep chain | sed 's/^/WIDE   /'
-  TGTC_NERF_NARROW=1 python tools/time_fused.py fp16x3 2>/dev/null | grep chain | sed 's/^/NARROW /'
+  TGTC_NERF_WIDE=1 python tools/time_fused.py fp16x3 2>/dev/null | grep chain | sed "s/^/WIDE   /"
+  python tools/time_fused.py fp16x3 2>/dev/null | grep chain | sed "s/^/NARROW /"
 done
