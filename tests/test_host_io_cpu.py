@@ -93,3 +93,24 @@ def test_image_transforms_match_torchvision_semantics():
     assert c.shape == (7, 9, 3) and np.array_equal(c[1:6, 1:8], a) and not c[0].any() and not c[:, 0].any()
     s = trans_test.style_image_array.__doc__
     assert "512" in s
+
+
+def test_image_writer_background_files(tmp_path):
+    """image_writer.ImageWriter: files appear after drain(), pixels unchanged, a failing file surfaces at drain()."""
+    import torch
+    from PIL import Image
+    from tgtc_style_amd import image_writer as iw
+    w = iw.ImageWriter(workers=3)
+    rng = np.random.default_rng(0)
+    imgs = [rng.integers(0, 256, (37, 53, 3), dtype=np.uint8) for _ in range(6)] + [rng.integers(0, 256, (20, 31), dtype=np.uint8)]
+    for i, a in enumerate(imgs):
+        w.save(str(tmp_path / ("%03d.png" % i)), a if i % 2 else torch.from_numpy(a))
+    w.drain()
+    for i, a in enumerate(imgs):
+        assert np.array_equal(np.asarray(Image.open(tmp_path / ("%03d.png" % i))), a)
+    w.save(str(tmp_path / "no_such_dir" / "x.png"), imgs[0])
+    w.save(str(tmp_path / "ok.png"), imgs[1])
+    with pytest.raises(OSError):
+        w.drain()
+    assert (tmp_path / "ok.png").exists()       # the other files of the batch are still written
+    w.drain()                                   # nothing pending: returns

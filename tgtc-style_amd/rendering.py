@@ -89,8 +89,15 @@ class RayRenderer:
 # Unlike the reference they return cleanly and require N_samples_fine > 0 (Q2).
 # =====================================================================================================
 def _save_png(path, arr):
-    from PIL import Image
-    Image.fromarray(np.asarray(arr).astype(np.uint8)).save(path)   # utils.py:463 to8b = uint8 cast
+    """utils.py:463 to8b = uint8 cast.  The file is encoded and written by the background writer (image_writer.py);
+    the drivers drain it before they return."""
+    from .image_writer import writer
+    writer().save(path, arr if isinstance(arr, torch.Tensor) else np.asarray(arr).astype(np.uint8))
+
+
+def _drain_images():
+    from .image_writer import writer
+    writer().drain()
 
 
 def _to_device(batch, device):
@@ -127,16 +134,18 @@ def _write_depth_rgb(sv_path, rgb, t, h, w, rgb_name, depth_name, eps=1e-7, dept
     reference's own host arithmetic."""
     if isinstance(rgb, torch.Tensor) and rgb.is_cuda:
         from . import utils
-        rgb8, depth8 = utils.frames_to_uint8(rgb, t, 1, eps)
-        rgb8, depth8 = rgb8.cpu().numpy().reshape(h, w, 3), depth8.cpu().numpy().reshape(h, w)
+        rgb8, depth8 = utils.frames_to_uint8(rgb, t, 1, eps)       # stay on the device: the writer copies them out
+        rgb8, depth8 = rgb8.reshape(h, w, 3), depth8.reshape(h, w)
+        if depth_channels == 3:
+            depth8 = depth8.unsqueeze(-1).expand(h, w, 3).contiguous()
     else:
         rgb, t = np.asarray(rgb, np.float32), np.asarray(t, np.float32)
         with np.errstate(invalid="ignore", divide="ignore"):
             sv_t = (t - t.min()) / ((t.max() - t.min() + eps) if eps else (t.max() - t.min()))
             rgb8 = np.array(rgb.reshape(h, w, 3) * 255, np.int32).astype(np.uint8)
             depth8 = np.array(sv_t.reshape(h, w) * 255, np.int32).astype(np.uint8)
-    if depth_channels == 3:
-        depth8 = np.broadcast_to(depth8[..., None], [h, w, 3])
+        if depth_channels == 3:
+            depth8 = np.ascontiguousarray(np.broadcast_to(depth8[..., None], [h, w, 3]))
     _save_png(os.path.join(sv_path, rgb_name), rgb8)
     _save_png(os.path.join(sv_path, depth_name), depth8)
 
@@ -190,6 +199,7 @@ def cal_geometry(model_forward, samp_func, dataloader, args, device, sv_path=Non
     if sv_path is not None:
         np.savez(os.path.join(sv_path, 'geometry'), coor_map=coor_map.reshape(-1, h, w, 3), cps=cps, hwf=ds.hwf,
                  near=ds.near, far=ds.far)
+    _drain_images()
     return rgb_map, t_map
 
 
@@ -255,6 +265,7 @@ def render_style(model_forward, samp_func, style_forward, concat_style_forward, 
                                  'style_%05d_fine_depth_%05d.png' % (gid // frame_num, gid % frame_num))
             image_no += 1
             pend_rgb, pend_t = pend_rgb[res:], pend_t[res:]
+    _drain_images()
     return pend_rgb.cpu().numpy(), pend_t.cpu().numpy()
 
 
@@ -298,4 +309,5 @@ def render_train_style(samp_func, model_forward, style_forward, concat_style_for
                                      os.path.basename(path).replace('_fine_', '_fine_depth_'), eps=0., depth_channels=3)
             img_count += 1
             it, rgbs, ts = 0, [], []
+    _drain_images()
     return img_count

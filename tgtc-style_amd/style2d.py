@@ -410,17 +410,22 @@ def stylize_frames(net, contents, style, output_path=None, style_name="style", s
     the reference does -- a zero row is prepended and the sum divided by rows-1 (:145,178) -- and written with the style
     image to `stylized_data.npz` under the reference's keys (:179), which is what its dataset reads back
     (dataset.py:437-440).  Returns (list of uint8 HWC images, style_features [1,1024] float32)."""
-    rows = np.zeros([1, 1024], dtype=np.float32)
-    images = []
+    from .image_writer import writer
+    feats, images = [], []
+    if output_path is not None:
+        os.makedirs(output_path, exist_ok=True)
     for cnt, content in enumerate(contents, start=1):
         image, feat, _ = stylize_frame(net, content, style)
-        rows = np.append(rows, [feat.detach().float().cpu().numpy().reshape(1024)], axis=0)
-        img8 = image[0].detach().mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).cpu().numpy()
+        feats.append(feat.detach().float().reshape(1024))         # stays on the device until the loop is done
+        img8 = image[0].detach().mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).contiguous()
         images.append(img8)
-        if output_path is not None:
-            from PIL import Image
-            os.makedirs(output_path, exist_ok=True)
-            Image.fromarray(img8).save('{:s}/{:03d}{:s}'.format(output_path, cnt, save_ext))
+        if output_path is not None:                                  # encoded and written in the background
+            writer().save('{:s}/{:03d}{:s}'.format(output_path, cnt, save_ext), img8)
+    writer().drain()
+    images = [im.cpu().numpy() for im in images]
+    rows = np.zeros([1, 1024], dtype=np.float32)
+    if feats:
+        rows = np.append(rows, torch.stack(feats).cpu().numpy(), axis=0)
     features = np.sum(rows, axis=0, keepdims=True) / (rows.shape[0] - 1)
     if output_path is not None:
         if style_image is None:

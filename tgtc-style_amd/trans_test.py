@@ -93,7 +93,8 @@ def transformer_render(content_dir, style_dir, output, save_ext=".jpg", content=
     style_img = style_image_array(style_path_for_list)
     rows = np.zeros([1, 1024], dtype=np.float32)
 
-    cnt = 0
+    from .image_writer import writer
+    cnt, feats = 0, []
     for content_path in content_paths:
         for style_path in style_paths:
             content_tensor = _to_tensor(Image.open(content_path))
@@ -102,10 +103,13 @@ def transformer_render(content_dir, style_dir, output, save_ext=".jpg", content=
             with torch.no_grad():
                 image, feat, _ = style2d.stylize_frame(net, content_tensor.cuda().unsqueeze(0), style_tensor.cuda().unsqueeze(0))
             cnt += 1
-            # torchvision.utils.save_image: x*255 + 0.5, clamped, uint8, HWC
-            img8 = image[0].detach().mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).cpu().numpy()
-            Image.fromarray(img8).save("{:s}/{:03d}{:s}".format(output, cnt, save_ext))
-            rows = np.append(rows, [feat.detach().float().cpu().numpy().reshape(1024)], axis=0)
+            # torchvision.utils.save_image: x*255 + 0.5, clamped, uint8, HWC; encoded and written in the background
+            img8 = image[0].detach().mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).contiguous()
+            writer().save("{:s}/{:03d}{:s}".format(output, cnt, save_ext), img8)
+            feats.append(feat.detach().float().reshape(1024))
+    writer().drain()
+    if feats:
+        rows = np.append(rows, torch.stack(feats).cpu().numpy(), axis=0)
 
     style_feature = np.sum(rows, axis=0, keepdims=True) / (rows.shape[0] - 1)
     np.savez(os.path.join(output, "stylized_data"), style_names=style_name, style_paths=style_path_for_list,
