@@ -86,6 +86,13 @@ int tgtc_s2d_mean_std(const float* feat, int C, int64_t HW, float eps, float* me
 int tgtc_s2d_adain(const float* content, int64_t HWc, const float* style, int64_t HWs, int C, float* stats, float* out,
                    void* stream);
 
+/* A dense layer on device pointers: y[M,N] = act(x[M,K] . W[N,K]^T + b[N]) (nn.Linear layout; b may be NULL; relu 0/1;
+ * precision TGTC_PREC_FP16 or TGTC_PREC_FP16X3).  For the few nn.Linear stacks of the reference that sit outside the
+ * fused kernels: the VAE encoder that initialises the latent table when no latent checkpoint exists
+ * (models.py:371-395 VAE_encoder, train_tgtcs.py:148-155). */
+int tgtc_s2d_linear(const float* x, int64_t M, int K, const float* W, const float* b, int N, int relu, int precision,
+                    float* y, void* stream);
+
 /* trans_test.py:172-173: bilinear resize, align_corners=True.  in [C,h,w] -> out [C,H,W]. */
 int tgtc_s2d_resize_bilinear(const float* in, int C, int h, int w, float* out, int H, int W, void* stream);
 /* trans_test.py:176: rows = hs_nchw.reshape(-1,512); feature = [rows.mean(0), rows.var(0)] (unbiased) -> [1024].

@@ -113,6 +113,15 @@ def latents_forward(sd, style_ids, frame_ids, sigma_scale=1.0, llff=True):
     return mu + sigma_scale * (z - mu)
 
 
+def vae_encode(sd, x, depth=4):
+    """VAE.encode(x, various=False) (reference models.py:390-395, :450-453): D-1 Linear+ReLU layers, then the mu and
+    log-variance heads.  x [S,1024] float32 -> (mu [S,32], log_var [S,32])."""
+    h = x
+    for i in range(depth - 1):
+        h = torch.relu(_lin(sd, "encoder.fc_layers.%d" % i, h))
+    return _lin(sd, "encoder.fc_layer_mu", h), _lin(sd, "encoder.fc_layer_log_var", h)
+
+
 def render_plain(sd_coarse, sd_fine, rays_o, rays_d, n_coarse, n_fine, near=0., far=1.):
     """The cal_geometry chain, one chunk.  rendering.py:27-51 (perturb=False, det fine sampling).
 

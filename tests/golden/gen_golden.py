@@ -492,9 +492,26 @@ def g11_llff_poses():
     save("g11_llff_poses", **out)
 
 
+def g12_vae():
+    """VAE.encode on three style-feature rows (train_tgtcs.py:148-155: the latent table's mu / logvar when no latent
+    checkpoint exists), and the shapes set_latents produces."""
+    vae = ref_models.VAE(data_dim=1024, latent_dim=32, W=512, D=4, kl_lambda=0.1).eval()
+    vae.load_state_dict(t(synth.vae_state(9)))
+    rng = np.random.default_rng(12)
+    feats = np.concatenate([rng.standard_normal((3, 512)) * 0.5, np.abs(rng.standard_normal((3, 512))) * 0.3], 1).astype(np.float32)
+    with torch.no_grad():
+        _, mu, logvar = vae.encode(torch.from_numpy(feats), various=False)
+    lat = ref_models.StyleLatents_variational(style_num=3, frame_num=5, latent_dim=32)
+    lat.style_latents_mu = torch.nn.Parameter(mu.detach())
+    lat.style_latents_logvar = torch.nn.Parameter(logvar.detach())
+    lat.set_latents()
+    save("g12_vae", style_features=feats, mu=mu, logvar=logvar, latents_shape=np.array(lat.latents.shape),
+         state_keys=np.array(sorted(vae.state_dict().keys())))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_rays, g2_coarse, g3_embed, g4_nerf, g5_composite, g6_fine, g7_style, g8_end_to_end, g9_style2d, g10_image,
-               g11_llff_poses):
+               g11_llff_poses, g12_vae):
         if not only or fn.__name__.split("_")[0] in only:
             fn()

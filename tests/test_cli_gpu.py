@@ -148,3 +148,47 @@ def test_cli_two_ranks_write_the_single_rank_images(tmp_path, shard):
     for n in names:
         with open(os.path.join(one, n), "rb") as a, open(os.path.join(two, n), "rb") as b:
             assert a.read() == b.read(), n
+
+
+def test_vae_latent_initialisation(tmp_path, golden):
+    """No latent checkpoint (train_tgtcs.py:128-155): the VAE encodes the style features left by the 2-D pass into the
+    latent table's mu / logvar, every frame's latent is drawn around them.  VAE.encode on the HIP GEMM vs the reference's
+    own outputs (golden g12); then the CLI on a scene directory in the reference's layout -- poses_bounds.npy,
+    stylized_gen_<factor>/stylized_data.npz, vae.pth, NNNNNN.tar, style_NNNNNN.tar -- without --synthetic."""
+    from tgtc_style_amd import models, synth, train_tgtcs
+    t = lambda sd: {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    g = golden("g12_vae")
+    vae = models.VAE(data_dim=1024, latent_dim=32, W=512, D=4)
+    vae.load_state_dict(t(synth.vae_state(9)))
+    vae.cuda()
+    z, mu, logvar = vae.encode(torch.from_numpy(g["style_features"]).cuda())
+    assert z is mu
+    assert float((mu.cpu() - torch.from_numpy(g["mu"])).abs().max()) <= 2e-5 * float(np.abs(g["mu"]).max())
+    assert float((logvar.cpu() - torch.from_numpy(g["logvar"])).abs().max()) <= 2e-5 * float(np.abs(g["logvar"]).max())
+    lat = models.StyleLatents_variational(style_num=3, frame_num=5, latent_dim=32).cuda()
+    lat.style_latents_mu, lat.style_latents_logvar = torch.nn.Parameter(mu), torch.nn.Parameter(logvar)
+    lat.set_latents(generator=torch.Generator().manual_seed(0))
+    assert tuple(lat.latents.shape) == tuple(g["latents_shape"]) and lat.latents.is_cuda
+    dev = (lat.latents.detach() - mu[:, None, :]) / torch.exp(0.5 * logvar)[:, None, :]          # ~ N(0,1)
+    assert abs(float(dev.mean())) < 0.2 and 0.8 < float(dev.std()) < 1.2
+
+    scene = tmp_path / "scene"
+    (scene / "stylized_gen_8.0").mkdir(parents=True)
+    np.save(scene / "poses_bounds.npy", golden("g11_llff_poses")["poses_arr"])
+    np.savez(scene / "stylized_gen_8.0" / "stylized_data", style_names={"s": 0}, style_paths="style/s.jpg",
+             style_images=np.zeros([1, 8, 8, 3], np.float32), style_features=g["style_features"][:1])
+    torch.save(t(synth.vae_state(9)), tmp_path / "vae.pth")
+    argv = ["--config", os.path.join(ROOT, "configs", "fern.txt"), "--basedir", str(tmp_path), "--datadir", str(scene), "--factor", "8",
+            "--vae_pth_path", str(tmp_path / "vae.pth"), "--chunk", "1024", "--batch_size", "100", "--render_train_style"]
+    with pytest.raises(SystemExit, match="no NeRF checkpoint"):
+        train_tgtcs.main(argv)
+    sv = os.path.join(str(tmp_path), "fern_style_style_nerf_relu_UseViewDir_ImgFactor8")
+    torch.save({"global_step": 7, "model": t(synth.nerf_state(0)), "model_fine": t(synth.nerf_state(1))}, os.path.join(sv, "000007.tar"))
+    torch.save({"global_step": 9, "model": t(synth.style_state(3)), "concat_model": t(synth.concat_state(2))},
+               os.path.join(sv, "style_000009.tar"))
+    out = train_tgtcs.main(argv)
+    names = sorted(os.listdir(out))
+    assert os.path.basename(out) == "render_train_9" and len(names) == 2 * 20 and names[0] == "style_00000_fine_00000.png"
+    # without the VAE file there is nothing to initialise the latents from
+    with pytest.raises(SystemExit, match="no latent checkpoint"):
+        train_tgtcs.main(argv[:argv.index("--vae_pth_path")] + ["--vae_pth_path", str(tmp_path / "missing.pth")] + argv[argv.index("--vae_pth_path") + 2:])

@@ -192,3 +192,16 @@ def test_g10_image_epilogue(golden):
     assert rgb8.dtype == np.uint8 and depth8.dtype == np.uint8
     assert np.array_equal(rgb8.reshape(frames, h, w, 3), g["rgb8"])
     assert np.array_equal(depth8.reshape(frames, h, w), g["depth8"])
+
+
+def test_g12_vae_encode(golden):
+    """oracle.fields.vae_encode vs the reference's VAE.encode(x, various=False) (same ATen ops: bit exact); the VAE
+    container of the package carries the reference's state-dict keys."""
+    from tgtc_style_amd import models
+    g = golden("g12_vae")
+    mu, logvar = fields.vae_encode(T(synth.vae_state(9)), tt(g["style_features"]))
+    close(mu, g["mu"])
+    close(logvar, g["logvar"])
+    vae = models.VAE(data_dim=1024, latent_dim=32, W=512, D=4)
+    assert sorted(vae.state_dict().keys()) == list(g["state_keys"])
+    vae.load_state_dict(T(synth.vae_state(9)))          # strict

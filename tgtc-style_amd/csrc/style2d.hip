@@ -1090,6 +1090,17 @@ extern "C" int tgtc_s2d_vgg_encode(const tgtc_style2d* h, const float* img, int 
     return emit(buf[0], H4 * W4, 512, relu4_1);
 }
 
+extern "C" int tgtc_s2d_linear(const float* x, int64_t M, int K, const float* W, const float* b, int N, int relu,
+                               int precision, float* y, void* stream) {
+    TGTC_REQUIRE(M >= 0 && M < 0x7fffffffLL && K > 0 && N > 0, "s2d_linear: bad shape");
+    TGTC_REQUIRE(precision == TGTC_PREC_FP16 || precision == TGTC_PREC_FP16X3, "s2d_linear: unknown precision %d", precision);
+    if (M == 0) return TGTC_OK;
+    TGTC_REQUIRE(x && W && y, "s2d_linear: null pointer");
+    tgtc_style2d h;
+    h.precision = precision;
+    return linear(&h, x, K, (int)M, K, W, b, N, y, N, nullptr, relu, as_stream(stream));
+}
+
 extern "C" int tgtc_s2d_mean_std(const float* feat, int C, int64_t HW, float eps, float* mean, float* std_,
                                  void* stream) {
     TGTC_REQUIRE(feat && mean && std_ && C > 0 && HW > 1, "mean_std: bad argument (needs HW > 1 for the unbiased variance)");

@@ -252,8 +252,39 @@ class StylePair(_Packed):
         return self._packed()
 
 
+class VAE(nn.Module):
+    """reference models.py:371-457 as a parameter container with the same state-dict keys; only what the render path
+    needs runs: `encode(x, various=False)` -> (z = mu, mu, log_var), the D-1 Linear+ReLU layers and the two heads of
+    VAE_encoder.forward (:390-395) on the HIP GEMM kernel (tgtc_s2d_linear).  The decoder's parameters are carried so
+    that the reference's vae.pth loads; sampling / losses belong to training."""
+
+    def __init__(self, data_dim, latent_dim, W=512, D=4, kl_lambda=0.1, precision="fp16x3"):
+        super().__init__()
+        self.data_dim, self.latent_dim, self.W, self.D, self.kl_lambda, self.precision = data_dim, latent_dim, W, D, kl_lambda, precision
+
+        def stack(first, out_name, out_dim):
+            m = nn.Module()
+            m.fc_layers = nn.ModuleList([nn.Linear(first if i == 0 else W, W) for i in range(D - 1)])
+            for name, dim in zip(out_name, out_dim):
+                setattr(m, name, nn.Linear(W, dim))
+            return m
+        self.encoder = stack(data_dim, ["fc_layer_mu", "fc_layer_log_var"], [latent_dim, latent_dim])
+        self.decoder = stack(latent_dim, ["output_layer"], [data_dim])
+
+    def encode(self, x, various=False):
+        from . import style2d
+        if various:
+            raise NotImplementedError("VAE.encode(various=True) draws a training-time sample; the render path reads mu / log_var")
+        h = x
+        for layer in self.encoder.fc_layers:
+            h = style2d.linear(h, layer.weight, layer.bias, relu=True, precision=self.precision)
+        mu = style2d.linear(h, self.encoder.fc_layer_mu.weight, self.encoder.fc_layer_mu.bias, precision=self.precision)
+        log_var = style2d.linear(h, self.encoder.fc_layer_log_var.weight, self.encoder.fc_layer_log_var.bias, precision=self.precision)
+        return mu, mu, log_var
+
+
 class StyleLatents_variational(nn.Module):
-    """reference models.py:475-506."""
+    """reference models.py:475-506, :535-539."""
 
     def __init__(self, **kwargs):
         super().__init__()
@@ -262,6 +293,15 @@ class StyleLatents_variational(nn.Module):
         self.style_latents_mu = nn.Parameter(torch.randn(self.style_num, self.latent_dim))
         self.style_latents_logvar = nn.Parameter(torch.randn(self.style_num, self.latent_dim))
         self.sigma_scale = 1.
+
+    def set_latents(self, generator=None):
+        """models.py:535-539 with reparameterize (:421-424): every frame's latent = mu + exp(0.5 logvar) * N(0,1).
+        Host-side initialisation of a parameter table (the draw is torch's generator, as in the reference)."""
+        shape = [self.style_num, self.frame_num, self.latent_dim]
+        mu = self.style_latents_mu.detach().unsqueeze(1).expand(shape)
+        std = torch.exp(0.5 * self.style_latents_logvar.detach()).unsqueeze(1).expand(shape)
+        eps = torch.randn(shape, generator=generator, device="cpu").to(mu.device)
+        self.latents = nn.Parameter(eps * std + mu)
 
     def forward(self, **kwargs):
         style_ids, frame_ids = kwargs['style_ids'], kwargs['frame_ids']

@@ -40,6 +40,7 @@ SIGNATURES = {
     "tgtc_s2d_vgg_encode": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p],
     "tgtc_s2d_mean_std": [c_void_p, c_int, c_int64, c_float, c_void_p, c_void_p, c_void_p],
+    "tgtc_s2d_linear": [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "tgtc_s2d_adain": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p],
     "tgtc_s2d_resize_bilinear": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     "tgtc_s2d_style_feature": [c_void_p, c_int, c_void_p, c_void_p],
@@ -194,6 +195,21 @@ def adaptive_instance_normalization(content_feat, style_feat):
     hip.check(lib.tgtc_s2d_adain(hip.ptr(c), c[0, 0].numel(), hip.ptr(s), s[0, 0].numel(), C, hip.ptr(stats),
                                  hip.ptr(out), hip.stream()))
     return out
+
+
+def linear(x, weight, bias=None, relu=False, precision="fp16x3"):
+    """nn.Linear (+ ReLU) on the HIP GEMM kernel: x [M,K], weight [N,K], bias [N] CUDA float32 -> [M,N]."""
+    hip.require_gpu(x, weight)
+    lib = hip.load()
+    x, weight = x.float().contiguous(), weight.detach().float().contiguous()
+    b = None if bias is None else bias.detach().float().contiguous()
+    M, K = x.shape
+    N = weight.shape[0]
+    assert weight.shape[1] == K
+    y = torch.empty(M, N, device=x.device)
+    hip.check(lib.tgtc_s2d_linear(hip.ptr(x), M, K, hip.ptr(weight), hip.ptr(b), N, int(relu), hip.PRECISIONS[precision],
+                                  hip.ptr(y), hip.stream()))
+    return y
 
 
 def resize_bilinear(img, size):

@@ -112,6 +112,25 @@ def latents_state(seed=4, style_num=1, frame_num=20, dim=LATENT):
             "style_latents_logvar": rng.standard_normal((style_num, dim)).astype(np.float32)}
 
 
+def vae_state(seed=9, data_dim=1024, latent_dim=LATENT, W=512, D=4):
+    """VAE parameters under the reference's key names (models.py:371-457: encoder.fc_layers.i, encoder.fc_layer_mu,
+    encoder.fc_layer_log_var, decoder.fc_layers.i, decoder.output_layer), nn.Linear default init scale."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    dim = data_dim
+    for i in range(D - 1):
+        sd["encoder.fc_layers.%d.weight" % i], sd["encoder.fc_layers.%d.bias" % i] = _linear(rng, W, dim, math.sqrt(2.0))
+        dim = W
+    sd["encoder.fc_layer_mu.weight"], sd["encoder.fc_layer_mu.bias"] = _linear(rng, latent_dim, dim)
+    sd["encoder.fc_layer_log_var.weight"], sd["encoder.fc_layer_log_var.bias"] = _linear(rng, latent_dim, dim)
+    dim = latent_dim
+    for i in range(D - 1):
+        sd["decoder.fc_layers.%d.weight" % i], sd["decoder.fc_layers.%d.bias" % i] = _linear(rng, W, dim, math.sqrt(2.0))
+        dim = W
+    sd["decoder.output_layer.weight"], sd["decoder.output_layer.bias"] = _linear(rng, data_dim, dim)
+    return sd
+
+
 def _xavier(rng, *shape):
     fan_out, fan_in = shape[0], int(np.prod(shape[1:]))
     a = math.sqrt(6.0 / (fan_in + fan_out))

@@ -183,10 +183,14 @@ def train(args):
         concat_model.load_state_dict(_t(synth.concat_state(2)))
         style_model.load_state_dict(_t(synth.style_state(3)))
 
+    # what the 2-D pass left next to the scene (dataset.py:437-440): style images, their 1024-d features, their number
+    from . import trans_test
+    stylized = trans_test.read_stylized_data(args.datadir, args.factor)
     if os.path.exists(os.path.join(args.datadir, 'poses_bounds.npy')):
         # rendering needs the cameras of the scene, not its images
         dataset = LlffPoseScene(args.datadir, args.factor, device=device,
-                                valid_frames=args.synthetic_frames if args.synthetic else None)
+                                valid_frames=args.synthetic_frames if args.synthetic else None,
+                                style_num=stylized["style_num"] if stylized else 1)
     elif args.synthetic:
         hw = args.synthetic_hw
         dataset = SyntheticScene(hw, hw, frames=20, valid_frames=args.synthetic_frames, device=device)
@@ -204,8 +208,23 @@ def train(args):
     ck = None if args.no_reload else _newest(sv_path, ['tar', 'latent'], ['style'])       # train_tgtcs.py:139-146
     if ck:
         latents.load_state_dict(torch.load(ck, map_location='cpu')['train_set_1'])
-    else:
+    elif stylized is not None and dataset.style_num == stylized["style_num"] and os.path.exists(args.vae_pth_path):
+        # train_tgtcs.py:128-155: no latent checkpoint -> the VAE encodes the style features into mu / logvar and every
+        # frame's latent is drawn around them
+        vae = models.VAE(data_dim=1024, latent_dim=args.vae_latent, W=args.vae_w, D=args.vae_d, kl_lambda=args.vae_kl_lambda)
+        vae.load_state_dict(torch.load(args.vae_pth_path, map_location='cpu'))
+        vae.eval().to(device)
+        feats = torch.from_numpy(np.asarray(stylized["style_features"], np.float32)).to(device)
+        _, mu, logvar = vae.encode(feats)
+        latents.style_latents_mu = torch.nn.Parameter(mu.detach())
+        latents.style_latents_logvar = torch.nn.Parameter(logvar.detach())
+        latents.set_latents()
+        print('Initializing Latent Model from', args.vae_pth_path)
+    elif args.synthetic:
         latents.load_state_dict(_t(synth.latents_state(4, style_num=dataset.style_num, frame_num=dataset.frame_num)))
+    else:
+        raise SystemExit("train_tgtcs: no latent checkpoint in %s and no stylized_data.npz + --vae_pth_path to initialise "
+                         "the latents from (use --synthetic for the seeded scene)" % sv_path)
     latents = latents.to(device)
 
     renderer = rendering.RayRenderer(model, model_fine, models.StylePair(concat_model, style_model))
