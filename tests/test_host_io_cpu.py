@@ -114,3 +114,47 @@ def test_image_writer_background_files(tmp_path):
         w.drain()
     assert (tmp_path / "ok.png").exists()       # the other files of the batch are still written
     w.drain()                                   # nothing pending: returns
+
+
+def test_checkpoint_files_round_trip(tmp_path):
+    """checkpoints.py: the reference's file names / dictionary layouts, its newest-file selection and its rotation."""
+    import torch
+    from tgtc_style_amd import checkpoints as ck, models, synth
+    t = lambda sd: {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+    class A:
+        use_viewdir, act_type, embed_freq_coor, embed_freq_dir = True, "relu", 10, 4
+        netdepth = netdepth_fine = 8
+        netwidth = netwidth_fine = 256
+        style_D, vae_latent, precision = 8, 32, "fp16x3"
+    m, mf = models.StyleNerf(A, mode="coarse"), models.StyleNerf(A, mode="fine")
+    m.load_state_dict(t(synth.nerf_state(0))), mf.load_state_dict(t(synth.nerf_state(1)))
+    cm, sm = models.StyleMLP_before_concat(A), models.StyleMLP_Wild_multilayers(A)
+    cm.load_state_dict(t(synth.concat_state(2))), sm.load_state_dict(t(synth.style_state(3)))
+    lat = models.StyleLatents_variational(style_num=1, frame_num=20, latent_dim=32)
+    d = str(tmp_path / "ckpts")
+    assert ck.load_nerf(d, m, mf) is None and ck.load_style(d, sm, cm) is None and not ck.load_latents(d, lat)
+    for step in (500, 1000, 1500):
+        p = ck.save_nerf(d, step, m, mf, keep=2)
+    assert os.path.basename(p) == "001500.tar" and sorted(os.listdir(d)) == ["001000.tar", "001500.tar"]       # rotated
+    sd = torch.load(p)
+    assert sorted(sd) == ["global_step", "model", "model_fine", "optimizer", "style_optimizer"]
+    ck.save_style(d, 120500, sm, cm)
+    ck.save_latents(d, 120500, lat)
+    assert sorted(os.listdir(d)) == ["001000.tar", "001500.tar", "latent_120500.tar", "style_120500.tar"]
+    m2, mf2 = models.StyleNerf(A, mode="coarse"), models.StyleNerf(A, mode="fine")
+    assert ck.load_nerf(d, m2, mf2) == 1500                      # the newest NeRF file, not the style / latent ones
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    cm2, sm2 = models.StyleMLP_before_concat(A), models.StyleMLP_Wild_multilayers(A)
+    assert ck.load_style(d, sm2, cm2) == 120500
+    assert all(torch.equal(a, b) for a, b in zip(sm.state_dict().values(), sm2.state_dict().values()))
+    lat2 = models.StyleLatents_variational(style_num=1, frame_num=20, latent_dim=32)
+    assert ck.load_latents(d, lat2) and torch.equal(lat.latents, lat2.latents)
+    # the 2-D module's three files are what trans_test.load_network reads back
+    from tgtc_style_amd import style2d
+    tr, dec, emb = style2d.Transformer(), style2d.Decoder(), style2d.PatchEmbed()
+    s2 = str(tmp_path / "pretrained")
+    ck.save_style2d(s2, 160000, tr, dec, emb)
+    assert sorted(os.listdir(s2)) == ["decoder_iter_160000.pth", "embedding_iter_160000.pth", "transformer_iter_160000.pth"]
+    assert sorted(torch.load(os.path.join(s2, "decoder_iter_160000.pth"))) == ["decoder", "step"]
+    assert trans_test._newest(s2, "transformer").endswith("transformer_iter_160000.pth")

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import config as cfg
-from . import models, rendering, synth, utils
+from . import checkpoints, models, rendering, synth, utils
 
 
 class ShardedScene:
@@ -124,11 +124,6 @@ def _t(sd):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
 
 
-def _newest(path, want, reject=()):
-    files = [f for f in sorted(os.listdir(path)) if 'tar' in f and all(w in f for w in want) and not any(r in f for r in reject)]
-    return os.path.join(path, files[-1]) if files else None
-
-
 def _init_distributed():
     """One process per GPU under torchrun (RANK / WORLD_SIZE / LOCAL_RANK); the process group comes up BEFORE the first
     HIP call of the process.  TGTC_DIST_BACKEND=gloo lets several ranks share a GPU (functional rehearsals, tests)."""
@@ -162,23 +157,17 @@ def train(args):
     concat_model = models.StyleMLP_before_concat(args).to(device)
     style_model = models.StyleMLP_Wild_multilayers(args).to(device)
     global_step = 0
-    ck = None if args.no_reload else _newest(sv_path, ['tar'], ['style', 'latent'])      # train_tgtcs.py:60-72
-    if ck:
-        sd = torch.load(ck, map_location='cpu')
-        global_step = sd['global_step']
-        model.load_state_dict(sd['model'])
-        model_fine.load_state_dict(sd['model_fine'])
+    step = None if args.no_reload else checkpoints.load_nerf(sv_path, model, model_fine)           # train_tgtcs.py:60-72
+    if step is not None:
+        global_step = step
     elif args.synthetic:
         model.load_state_dict(_t(synth.nerf_state(0)))
         model_fine.load_state_dict(_t(synth.nerf_state(1)))
     else:
         raise SystemExit("train_tgtcs: no NeRF checkpoint in %s (use --synthetic for the seeded scene)" % sv_path)
-    ck = None if args.no_reload else _newest(sv_path, ['tar', 'style'], ['latent'])       # train_tgtcs.py:74-82
-    if ck:
-        sd = torch.load(ck, map_location='cpu')
-        global_step = sd['global_step']
-        style_model.load_state_dict(sd['model'])
-        concat_model.load_state_dict(sd['concat_model'])
+    step = None if args.no_reload else checkpoints.load_style(sv_path, style_model, concat_model)   # train_tgtcs.py:74-82
+    if step is not None:
+        global_step = step
     elif args.synthetic:
         concat_model.load_state_dict(_t(synth.concat_state(2)))
         style_model.load_state_dict(_t(synth.style_state(3)))
@@ -205,9 +194,8 @@ def train(args):
         dataset.set_sharding(rank, world, args.shard, dist)
     latents = models.StyleLatents_variational(style_num=dataset.style_num, frame_num=dataset.frame_num,
                                               latent_dim=args.vae_latent).to(device)
-    ck = None if args.no_reload else _newest(sv_path, ['tar', 'latent'], ['style'])       # train_tgtcs.py:139-146
-    if ck:
-        latents.load_state_dict(torch.load(ck, map_location='cpu')['train_set_1'])
+    if not args.no_reload and checkpoints.load_latents(sv_path, latents):                  # train_tgtcs.py:139-146
+        pass
     elif stylized is not None and dataset.style_num == stylized["style_num"] and os.path.exists(args.vae_pth_path):
         # train_tgtcs.py:128-155: no latent checkpoint -> the VAE encodes the style features into mu / logvar and every
         # frame's latent is drawn around them
