@@ -192,3 +192,34 @@ def test_vae_latent_initialisation(tmp_path, golden):
     # without the VAE file there is nothing to initialise the latents from
     with pytest.raises(SystemExit, match="no latent checkpoint"):
         train_tgtcs.main(argv[:argv.index("--vae_pth_path")] + ["--vae_pth_path", str(tmp_path / "missing.pth")] + argv[argv.index("--vae_pth_path") + 2:])
+
+
+def _batch_rank(rank, world, port, argv):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), TGTC_DIST_BACKEND="gloo")
+    from tgtc_style_amd import render_batch
+    render_batch.main(argv)
+
+
+def test_batch_render_of_scene_configs(tmp_path):
+    """render_batch (BASELINE config 5): several scene configs in one job, two ranks with frames dealt round-robin; every
+    scene's files are the ones the one-scene, one-rank CLI writes."""
+    import torch.multiprocessing as mp
+    from tgtc_style_amd import render_batch, train_tgtcs
+    scenes = ["fern", "trex", "horns"]
+    rest = ["--synthetic", "--synthetic_hw", "24", "--synthetic_frames", "3", "--chunk", "1024", "--batch_size", "576",
+            "--render_valid_style", "--precision", "fp16"]          # config 5 names the fp16 path
+    one = tmp_path / "one"
+    ref = {s: train_tgtcs.main(["--config", os.path.join(ROOT, "configs", s + ".txt"), "--basedir", str(one)] + rest) for s in scenes}
+    two = tmp_path / "two"
+    argv = ["--configs"] + [os.path.join(ROOT, "configs", s + ".txt") for s in scenes] + ["--", "--basedir", str(two)] + rest
+    mp.start_processes(_batch_rank, args=(2, 29531, argv), nprocs=2, join=True, start_method="spawn")
+    for s in scenes:
+        out = ref[s].replace(str(one), str(two))
+        names = sorted(os.listdir(ref[s]))
+        assert len(names) == 6 and sorted(os.listdir(out)) == names
+        for n in names:
+            assert open(os.path.join(out, n), "rb").read() == open(os.path.join(ref[s], n), "rb").read(), (s, n)
+    # one process, no torchrun: the same loop
+    outs = render_batch.main(["--configs", os.path.join(ROOT, "configs", "orchids.txt"), "--", "--basedir", str(tmp_path / "three")] + rest)
+    assert len(outs) == 1 and len(os.listdir(outs[0])) == 6

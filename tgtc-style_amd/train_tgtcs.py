@@ -133,6 +133,8 @@ def _init_distributed():
         return 0, 1, 0, None
     import torch.distributed as dist
     backend = os.environ.get("TGTC_DIST_BACKEND", "nccl")
+    if dist.is_initialized():          # a batch of scenes in one process (render_batch.py): the group is already up
+        return rank, world, (local if backend == "nccl" else local % max(torch.cuda.device_count(), 1)), dist
     if backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
