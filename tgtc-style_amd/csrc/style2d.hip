@@ -8,6 +8,7 @@
 // patch embedding or a 3x3 convolution with reflection padding and nearest x2 upsampling folded into
 // the gather (implicit GEMM over token-major / NHWC feature maps: a k-step is 32 consecutive channels of
 // one tap, i.e. one 128-byte line per row).
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -135,8 +136,8 @@ __device__ __forceinline__ void put4(half_t* hi, half_t* lo, const float (&v)[4]
 
 // B operand: either rows of W [N][K] (nn.Linear / conv weights, BL = DenseRows) or, with B_KMAJOR, a
 // k-major matrix B[k][n] = p[k*ld + n] (the V operand of attention).
-// WT = 16x16 accumulator tiles per wave and dimension: 4 -> 128x128 workgroup tiles, 2 -> 64x64 (chosen by launch_gemm
-// when 128x128 tiles would leave most of the 256 CUs idle: a [2500,512] projection is only 20x4 of them).
+// WT = 16x16 accumulator tiles per wave and dimension: 4 -> 128x128 workgroup tiles, 2 -> 64x64, 1 -> 32x32 (launch_gemm
+// picks; a [2500,512] projection is only 20x4 tiles of 128x128 on 256 CUs).
 template <class AL, bool SPLIT, bool B_KMAJOR, int WT>
 __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut out, int M, int N, int K) {
     constexpr int NP = SPLIT ? 2 : 1;
@@ -639,23 +640,30 @@ struct tgtc_style2d {
 
 namespace tgtc {
 
+// Tile choice by measurement (profiles/r2_kernel_variants.md section 8): these GEMMs are small (a [2500,512] projection is
+// 1.3 GFLOP) and latency-bound, so they want workgroups, not big tiles.  64x64 tiles beat 128x128 everywhere, the 400x400
+// VGG convolutions included; when even 64x64 leaves fewer than ~1.5 workgroups per CU (the 320-workgroup projections),
+// 32x32 tiles quadruple the grid.  The k-major loader (attention's V operand) only exists at 128x128.
 template <class AL, bool KM>
 static int launch_gemm(const tgtc_style2d* h, AL al, DenseRows bl, GemmOut out, int M, int N, int K, int batch,
                        hipStream_t st) {
     if (M <= 0 || N <= 0) return TGTC_OK;
-    const long long big = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch;
-    if (KM || big >= 256) {   // 128x128 tiles fill the chip (or the k-major loader, which only exists at that size)
+    const bool split = h->precision != TGTC_PREC_FP16;
+    if constexpr (KM) {
         dim3 grid((M + 127) / 128, (N + 127) / 128, batch);
-        if (h->precision == TGTC_PREC_FP16)
-            gemm_kernel<AL, false, KM, 4><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
-        else
-            gemm_kernel<AL, true, KM, 4><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
-    } else if constexpr (!KM) {
-        dim3 grid((M + 63) / 64, (N + 63) / 64, batch);
-        if (h->precision == TGTC_PREC_FP16)
-            gemm_kernel<AL, false, false, 2><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
-        else
-            gemm_kernel<AL, true, false, 2><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+        if (split) gemm_kernel<AL, true, true, 4><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+        else gemm_kernel<AL, false, true, 4><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+    } else {
+        const long long mid = (long long)((M + 63) / 64) * ((N + 63) / 64) * batch;
+        if (mid < 400) {
+            dim3 grid((M + 31) / 32, (N + 31) / 32, batch);
+            if (split) gemm_kernel<AL, true, false, 1><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+            else gemm_kernel<AL, false, false, 1><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+        } else {
+            dim3 grid((M + 63) / 64, (N + 63) / 64, batch);
+            if (split) gemm_kernel<AL, true, false, 2><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+            else gemm_kernel<AL, false, false, 2><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+        }
     }
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;

@@ -10,7 +10,8 @@ for p in glob.glob(root+"/stats/**/*kernel_stats.csv", recursive=True):
     rows=list(csv.DictReader(open(p)))
     rows=[r for r in rows if "fused_render" not in r["Name"]]
     tot=sum(float(r["TotalDurationNs"]) for r in rows)
+    frames=max(1,sum(int(r["Calls"]) for r in rows if "style_feature_kernel" in r["Name"]))   # one call per stylised frame
     for r in sorted(rows,key=lambda r:-float(r["TotalDurationNs"]))[:16]:
-        print("%8.3f ms/frame  avg %8.1f us x%-5s %s" % (float(r["TotalDurationNs"])/1e6/8, float(r["AverageNs"])/1e3, r["Calls"], r["Name"][:120]))
-    print("total %.2f ms / 8 frames" % (tot/1e6/8))
+        print("%8.3f ms/frame  avg %8.1f us x%-5s %s" % (float(r["TotalDurationNs"])/1e6/frames, float(r["AverageNs"])/1e3, r["Calls"], r["Name"][:120]))
+    print("total %.2f ms per frame over %d frames (all kernels of the process except the ray kernel, set-up copies included)" % (tot/1e6/frames, frames))
 PY
