@@ -9,6 +9,7 @@
 // the gather (implicit GEMM over token-major / NHWC feature maps: a k-step is 32 consecutive channels of
 // one tap, i.e. one 128-byte line per row).
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <string>
@@ -304,7 +305,8 @@ template <bool SPLIT>
 __global__ void __launch_bounds__(256) attn_kernel(const half_t* __restrict__ qh, const half_t* __restrict__ ql,
                                                    const half_t* __restrict__ kh, const half_t* __restrict__ kl,
                                                    const half_t* __restrict__ vth, const half_t* __restrict__ vtl,
-                                                   int L, int S, int S_pad, float* __restrict__ out) {
+                                                   int L, int S, int S_pad, float* __restrict__ out,
+                                                   float* __restrict__ part_o, float* __restrict__ part_ml) {
     constexpr int NP = SPLIT ? 2 : 1;
     __shared__ __attribute__((aligned(16))) half_t sK[NP][64][kAttnLd];
     __shared__ __attribute__((aligned(16))) half_t sV[NP][64][kAttnLd];   // [d][key]
@@ -343,8 +345,13 @@ __global__ void __launch_bounds__(256) attn_kernel(const half_t* __restrict__ qh
             }
         }
     };
-    fetch(0);
-    for (int key0 = 0; key0 < S; key0 += 64) {
+    // key split (gridDim.z > 1): this workgroup owns tiles [t0, t1) of the S_pad/64 key tiles and leaves an unnormalised
+    // partial result (O, running max, running sum) for attn_combine_kernel -- 1 250 query waves alone are ~1.2 per SIMD
+    const int n_tiles = S_pad / 64;
+    const int key_begin = (int)((long long)blockIdx.z * n_tiles / gridDim.z) * 64;
+    const int key_end = min(S, (int)((long long)(blockIdx.z + 1) * n_tiles / gridDim.z) * 64);
+    fetch(key_begin);
+    for (int key0 = key_begin; key0 < key_end; key0 += 64) {
         __syncthreads();   // the previous tile is consumed
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -356,7 +363,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const half_t* __restrict__ qh
             }
         }
         __syncthreads();
-        if (key0 + 64 < S) fetch(key0 + 64);
+        if (key0 + 64 < key_end) fetch(key0 + 64);
 
         // S^T tiles: keys 16kt + 4g + r, query n
         float4v sc[4];
@@ -423,6 +430,19 @@ __global__ void __launch_bounds__(256) attn_kernel(const half_t* __restrict__ qh
     }
     lsum += __shfl_xor(lsum, 16);
     lsum += __shfl_xor(lsum, 32);
+    if (gridDim.z > 1) {
+        if (qok) {
+            float* po = part_o + ((long long)blockIdx.z * L + qi) * 512 + head * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<float4*>(po + 16 * dt + 4 * g) = float4{O[dt][0], O[dt][1], O[dt][2], O[dt][3]};
+            if (g == 0) {
+                float* pm = part_ml + (((long long)blockIdx.z * L + qi) * 8 + head) * 2;
+                pm[0] = m, pm[1] = lsum;
+            }
+        }
+        return;
+    }
     if (qok) {
         const float inv = 1.0f / lsum;
 #pragma unroll
@@ -431,6 +451,28 @@ __global__ void __launch_bounds__(256) attn_kernel(const half_t* __restrict__ qh
             *reinterpret_cast<float4*>(out + (long long)qi * 512 + head * 64 + 16 * dt + 4 * g) = o4;
         }
     }
+}
+
+// out[q, head*64 + d] = sum_z O_z e^(m_z - M) / sum_z l_z e^(m_z - M),  M = max_z m_z   (the key splits of attn_kernel)
+__global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                           int L, int nsplit, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;     // one float4 of the output
+    if (i >= (long long)L * 128) return;
+    const long long q = i >> 7;
+    const int c4 = (int)(i & 127), head = c4 >> 4;
+    float M = -INFINITY;
+    for (int z = 0; z < nsplit; ++z) M = fmaxf(M, part_ml[(((long long)z * L + q) * 8 + head) * 2]);
+    float den = 0.0f;
+    float4 acc{0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < nsplit; ++z) {
+        const float* ml = part_ml + (((long long)z * L + q) * 8 + head) * 2;
+        const float w = expf(ml[0] - M);
+        den += ml[1] * w;
+        const float4 o = *reinterpret_cast<const float4*>(part_o + ((long long)z * L + q) * 512 + 4 * c4);
+        acc.x += o.x * w, acc.y += o.y * w, acc.z += o.z * w, acc.w += o.w * w;
+    }
+    const float inv = 1.0f / den;
+    *reinterpret_cast<float4*>(out + q * 512 + 4 * c4) = float4{acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv};
 }
 
 // ------------------------------------------------------------------------------------------------ small kernels
@@ -746,12 +788,27 @@ static int mha(const tgtc_style2d* h, const std::string& p, const float* q_in, l
         attn_prep_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(Q, 512, L, Kp, ldK, V, ldV, S, S_pad, qh, ql, kh, kl,
                                                                              vth, vtl);
         TGTC_LAUNCH_CHECK();
-        const dim3 grid((L + 63) / 64, 8);
+        // key splits: enough of them for ~4 query-waves per SIMD (1 024 SIMDs), at most one per key tile
+        // (measured at 2 500 tokens, whole 2-D pass: 1 split 6.00 ms, 2: 5.52, 4: 5.43, 8: 5.40)
+        const long long waves = (long long)((L + 15) / 16) * 8;
+        int nsplit = (int)std::min<long long>(8, (4096 + waves - 1) / waves);
+        nsplit = std::max(1, std::min(nsplit, S_pad / 64));
+        float *part_o = nullptr, *part_ml = nullptr;
+        if (nsplit > 1) {
+            part_o = ws.take((size_t)nsplit * L * 512);
+            part_ml = ws.take((size_t)nsplit * L * 16);
+            if (!ws.ok) return fail(TGTC_ERR_ARG, "style2d: workspace too small for attention (L=%d, S=%d)", L, S);
+        }
+        const dim3 grid((L + 63) / 64, 8, nsplit);
         if (h->precision == TGTC_PREC_FP16)
-            attn_kernel<false><<<grid, 256, 0, st>>>(qh, ql, kh, kl, vth, vtl, L, S, S_pad, O);
+            attn_kernel<false><<<grid, 256, 0, st>>>(qh, ql, kh, kl, vth, vtl, L, S, S_pad, O, part_o, part_ml);
         else
-            attn_kernel<true><<<grid, 256, 0, st>>>(qh, ql, kh, kl, vth, vtl, L, S, S_pad, O);
+            attn_kernel<true><<<grid, 256, 0, st>>>(qh, ql, kh, kl, vth, vtl, L, S, S_pad, O, part_o, part_ml);
         TGTC_LAUNCH_CHECK();
+        if (nsplit > 1) {
+            attn_combine_kernel<<<(unsigned)(((long long)L * 128 + 255) / 256), 256, 0, st>>>(part_o, part_ml, L, nsplit, O);
+            TGTC_LAUNCH_CHECK();
+        }
     }
     return linear(h, O, 512, L, 512, ow, ob, 512, out, 512, nullptr, 0, st);
 }
@@ -832,7 +889,7 @@ static int decoder_layer(const tgtc_style2d* h, const std::string& p, const floa
 
 static size_t layer_ws_floats(size_t L, size_t S) {
     // generous upper bound for one encoder / decoder layer incl. attention scratch (256-byte rounding included)
-    return 1536 * S + 16 * 512 * (L + S + 64) + 2048 * (L + S) + 64 * 64;
+    return 1536 * S + 24 * 512 * (L + S + 64) + 2048 * (L + S) + 64 * 64;
 }
 
 static int conv3x3(const tgtc_style2d* h, const float* w, const float* b, const float* in, int Hs, int Ws, int up,
