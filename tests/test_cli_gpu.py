@@ -223,3 +223,17 @@ def test_batch_render_of_scene_configs(tmp_path):
     # one process, no torchrun: the same loop
     outs = render_batch.main(["--configs", os.path.join(ROOT, "configs", "orchids.txt"), "--", "--basedir", str(tmp_path / "three")] + rest)
     assert len(outs) == 1 and len(os.listdir(outs[0])) == 6
+
+
+def test_cli_whole_image_batches_equal_literal_batches(tmp_path):
+    """The CLI renders whole images per call; --literal_batches feeds --batch_size rays at a time like the reference's
+    loader.  Same files either way (device-generated rays, per-ray seeded jitter)."""
+    from tgtc_style_amd import train_tgtcs
+    base = ["--config", os.path.join(ROOT, "configs", "fern.txt"), "--synthetic", "--synthetic_hw", "40", "--synthetic_frames", "2",
+            "--chunk", "1024", "--batch_size", "300", "--render_valid_style"]
+    a = train_tgtcs.main(base + ["--basedir", str(tmp_path / "a")])
+    b = train_tgtcs.main(base + ["--basedir", str(tmp_path / "b"), "--literal_batches"])
+    names = sorted(os.listdir(a))
+    assert len(names) == 4 and sorted(os.listdir(b)) == names
+    for n in names:
+        assert open(os.path.join(a, n), "rb").read() == open(os.path.join(b, n), "rb").read(), n

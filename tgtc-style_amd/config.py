@@ -35,6 +35,9 @@ EXTRA = {
     "precision": (str, "fp16x3"),      # fp16x3 (fp32-equivalent, default) | fp16mx | fp16, or "coarse+fine" e.g. fp16x3+fp16mx
     "shard": (str, "frames"),          # under torchrun: frames = whole images round-robin over the ranks, rank-local files;
                                        # rays = contiguous ray ranges of every image + one all-gather, rank 0 writes
+    "literal_batches": (None, False),  # render --batch_size rays per call like the reference; default: whole images per call
+                                       # (rays come from the device and the stratified jitter is seeded per ray, so an image
+                                       # does not depend on how its rays are batched)
     "synthetic": (None, False),        # no dataset / checkpoints: seeded weights + closed-form camera path
     "synthetic_hw": (int, 400),        # frame size of the synthetic scene
     "synthetic_frames": (int, 2),      # frames of the synthetic validation path

@@ -194,6 +194,10 @@ def train(args):
             raise SystemExit("train_tgtcs: the geometry pass (--render_valid / --render_train) writes one scene-wide "
                              "geometry.npz and runs on one GPU; the stylised renders shard (--shard frames|rays)")
         dataset.set_sharding(rank, world, args.shard, dist)
+    # rays per render call: the reference feeds --batch_size rays at a time from its host loader; with device-generated rays
+    # a whole image (this rank's part of it) per call keeps the persistent kernels busy -- 78 calls of 2 048 rays cost a
+    # 400x400 frame ~30 ms of launch gaps -- and gives the same pixels
+    batch_size = args.batch_size if args.literal_batches else max(args.batch_size, dataset.rays_per_image())
     latents = models.StyleLatents_variational(style_num=dataset.style_num, frame_num=dataset.frame_num,
                                               latent_dim=args.vae_latent).to(device)
     if not args.no_reload and checkpoints.load_latents(sv_path, latents):                  # train_tgtcs.py:139-146
@@ -229,7 +233,7 @@ def train(args):
             out = os.path.join(sv_path, 'render_valid_' + str(global_step))
             model.set_enable_style(True), model_fine.set_enable_style(True)
             dataset.mode = 'valid_style'
-            rendering.render_style(dataloader=_Loader(dataset, args.batch_size), sv_path=out, **common, **styled)
+            rendering.render_style(dataloader=_Loader(dataset, batch_size), sv_path=out, **common, **styled)
             print('Done, saving to', out)
             return out
         if args.render_train_style:
@@ -241,7 +245,7 @@ def train(args):
         if args.render_valid or args.render_train:
             out = os.path.join(sv_path, 'nerf_gen_data2')
             dataset.mode = 'train' if args.render_train else 'valid'
-            rendering.cal_geometry(dataloader=_Loader(dataset, args.batch_size), sv_path=out,
+            rendering.cal_geometry(dataloader=_Loader(dataset, batch_size), sv_path=out,
                                    renderer=rendering.RayRenderer(model, model_fine), **common)
             print('Done, saving to', out)
             return out
