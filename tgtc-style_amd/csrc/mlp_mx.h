@@ -209,15 +209,6 @@ __device__ __forceinline__ u6v cvt_fp6(half8 a, half8 b, half8 c, half8 d, float
 // v_fma_mixlo/mixhi_f16 (v * 1.0 - h in fp32, rounded once to fp16).  lo is NOT pre-scaled: it may be an fp16
 // subnormal (|lo| <= 2^-12 h), which v_cvt_scalef32_pk32_fp6_f16 takes like any other value, and the block scale of
 // the lo operand carries the 2^-11 instead.
-__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hpk, unsigned& lpk) {
-    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-    typedef float float2v __attribute__((ext_vector_type(2)));
-    v0 = relu(v0), v1 = relu(v1);
-    hpk = __builtin_bit_cast(unsigned, __builtin_convertvector((float2v{v0, v1}), half2v));
-    lpk = 0;
-    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(lpk) : "v"(v0), "v"(hpk));
-    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lpk) : "v"(v1), "v"(hpk));
-}
 __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
     typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, b)));
@@ -227,11 +218,6 @@ __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
 __device__ __forceinline__ int block_exp_byte(unsigned mxk) {
     const unsigned m = max(mxk & 0xffffu, mxk >> 16);
     return (int)(m >> 10) + 111;
-}
-__device__ __forceinline__ void set_pair(half8& v, int e0, unsigned pk) {
-    u4 r = __builtin_bit_cast(u4, v);
-    r[e0 >> 1] = pk;
-    v = __builtin_bit_cast(half8, r);
 }
 
 // Activations of one layer as the next layer's B operands: h[4*NKB] fp16 k-steps, h6 / l6 fp6 blocks,
