@@ -63,6 +63,16 @@ __device__ __forceinline__ void lds_dma16_t(const char* gsrc, char* lds_dst) {
     }
 }
 __device__ __forceinline__ void lds_dma16(const char* gsrc, char* lds_dst) { lds_dma16_t<kAsmDmaDefault>(gsrc, lds_dst); }
+// The same with the address split as the instruction wants it: a wave-uniform 64-bit base in SGPRs, a 32-bit per-lane
+// offset and a 13-bit immediate -- no 64-bit VALU add per instruction (the builtin never selects this form: it always
+// adds up a per-lane 64-bit address with v_lshl_add_u64).  The immediate is added to BOTH addresses -- the global one and
+// the LDS destination (M0 + offset + lane*16) -- so `lds_dst` is the destination of IMM = 0.
+template <int IMM>
+__device__ __forceinline__ void lds_dma16_s(const char* sbase, unsigned voff, char* lds_dst) {
+    static_assert(IMM >= 0 && IMM < 4096, "global instruction offset field");
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)TGTC_LPTR(lds_dst));
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(sbase), "s"(l), "n"(IMM) : "memory");
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -165,8 +175,11 @@ struct WeightStream {
     // LDS reads this window issues (fragments 2k, 2k+1 of the NEXT group while 2k < G), hi (+ lo) each
     static constexpr int reads_in_window(int f) { return (2 * (f % G) < G ? 2 : 0) * (C::SPLIT ? 2 : 1); }
 
-    const char* src[Map::NSEG];  // per-lane: segment stream + wave*GPC*1024 + lane*16
+    // stream pointers: per lane (segment stream + wave*GPC*1024 + lane*16) for the builtin DMA; with ASM_DMA the
+    // wave-uniform stream base, the per-lane part being `voff` (lds_dma16_s)
+    const char* src[Map::NSEG];
     const char* next;            // PERSIST: the same for the stream of the next pass
+    unsigned voff;               // wave*GPC*1024 + lane*16
     char* lds_wave;              // wave-uniform: ring + wave*GPC*1024
     lds_cptr lane_lo;  // ring + lane*16            (ring bytes [0, 64K))
     lds_cptr lane_hi;  // ring + 65536 + lane*16    (ring bytes [64K, 128K))
@@ -174,7 +187,8 @@ struct WeightStream {
 
     __device__ __forceinline__ void init(const char* const (&streams)[Map::NSEG], char* smem, int wave, int lane) {
 #pragma unroll
-        for (int i = 0; i < Map::NSEG; ++i) src[i] = streams[i] + wave * (C::GPC * 1024) + lane * 16;
+        for (int i = 0; i < Map::NSEG; ++i) src[i] = lane_src(streams[i], wave, lane);
+        voff = wave * (C::GPC * 1024) + lane * 16;
         lds_wave = smem + wave * (C::GPC * 1024);
         lane_lo = opaque((lds_cptr)smem + lane * 16);
         lane_hi = opaque((lds_cptr)smem + (C::RING_BYTES > 65536 ? 65536 : 0) + lane * 16);
@@ -185,31 +199,37 @@ struct WeightStream {
             if (ch >= Map::chunk0(i)) s = i;
         return s;
     }
+    template <size_t OFF, int SLOT>
+    __device__ __forceinline__ void issue_chunk(const char* base) const {
+        // launder the base: inside a persistent tile loop every chunk address is loop invariant, and hipcc would
+        // otherwise hoist hundreds of 64-bit addresses into the pre-header and spill them
+        if constexpr (ASM_DMA) {
+            asm volatile("" : "+s"(base));
+            const char* b = base + OFF;
+            static_for<C::GPC>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                lds_dma16_s<j * 1024>(b, voff, lds_wave + SLOT * kChunkBytes);
+            });
+        } else {
+            asm volatile("" : "+v"(base));
+#pragma unroll
+            for (int j = 0; j < C::GPC; ++j) lds_dma16_t<false>(base + OFF + j * 1024, lds_wave + SLOT * kChunkBytes + j * 1024);
+        }
+    }
     template <int CH>
     __device__ __forceinline__ void issue() const {
         if constexpr (CH < PADC) {
             constexpr int seg = seg_of(CH);
-            constexpr size_t off = (size_t)(CH - Map::chunk0(seg)) * kChunkBytes;
-            // launder the base: inside a persistent tile loop every chunk address is loop invariant, and hipcc
-            // would otherwise hoist hundreds of 64-bit per-lane addresses into the pre-header and spill them
-            const char* base = src[seg];
-            asm volatile("" : "+v"(base));
-#pragma unroll
-            for (int j = 0; j < C::GPC; ++j)
-                lds_dma16_t<ASM_DMA>(base + off + j * 1024, lds_wave + (CH % C::SLOTS) * kChunkBytes + j * 1024);
+            issue_chunk<(size_t)(CH - Map::chunk0(seg)) * kChunkBytes, CH % C::SLOTS>(src[seg]);
         } else if constexpr (PERSIST) {
             static_assert(CH < PADC + C::SLOTS, "look-ahead beyond the next pass's first ring");
-            constexpr size_t off = (size_t)(CH - PADC) * kChunkBytes;
-            const char* base = next;
-            asm volatile("" : "+v"(base));
-#pragma unroll
-            for (int j = 0; j < C::GPC; ++j)
-                lds_dma16_t<ASM_DMA>(base + off + j * 1024, lds_wave + (CH % C::SLOTS) * kChunkBytes + j * 1024);
+            issue_chunk<(size_t)(CH - PADC) * kChunkBytes, CH % C::SLOTS>(next);
         }
     }
     // PERSIST: the per-lane source pointer of a packed stream for this wave / lane
     __device__ __forceinline__ static const char* lane_src(const char* stream, int wave, int lane) {
-        return stream + wave * (C::GPC * 1024) + lane * 16;
+        if constexpr (ASM_DMA) return stream;
+        else return stream + wave * (C::GPC * 1024) + lane * 16;
     }
     // PERSIST, once per kernel: chunks 0 .. SLOTS-2 of the first stream (`next`), the state every enter() expects
     __device__ __forceinline__ void persist_prologue() const {
