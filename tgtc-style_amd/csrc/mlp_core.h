@@ -410,8 +410,8 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hpk, un
     typedef float float2v __attribute__((ext_vector_type(2)));
     v0 = relu(v0), v1 = relu(v1);
     hpk = __builtin_bit_cast(unsigned, __builtin_convertvector((float2v{v0, v1}), half2v));
-    lpk = 0;
-    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(lpk) : "v"(v0), "v"(hpk));
+    // (mixlo leaves the upper half of its destination alone, mixhi then writes it: no zero-initialisation needed)
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lpk) : "v"(v0), "v"(hpk));
     asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lpk) : "v"(v1), "v"(hpk));
 }
 __device__ __forceinline__ void set_pair(half8& v, int e0, unsigned pk) {

@@ -122,12 +122,12 @@ template <bool SPLIT>
 __device__ __forceinline__ void put4(half_t* hi, half_t* lo, const float (&v)[4]) {
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     typedef float float2v __attribute__((ext_vector_type(2)));
-    unsigned h[2], l[2] = {0u, 0u};
+    unsigned h[2], l[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         h[p] = __builtin_bit_cast(unsigned, __builtin_convertvector((float2v{v[2 * p], v[2 * p + 1]}), half2v));
         if constexpr (SPLIT) {
-            asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(l[p]) : "v"(v[2 * p]), "v"(h[p]));
+            asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l[p]) : "v"(v[2 * p]), "v"(h[p]));
             asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l[p]) : "v"(v[2 * p + 1]), "v"(h[p]));
         }
     }
