@@ -21,6 +21,13 @@
 #pragma once
 #include "mlp_core.h"
 
+// 1: the fp6 correction products accumulate into the row tile's main accumulator (one dependent chain; the two waves of
+// a SIMD cover each other's MFMA latency); 0: a separate correction accumulator summed in the epilogue (round 1).
+// Measured 101.5 -> 100.2 ms on the headline frame (profiles/r2_kernel_variants.md section 13).
+#ifndef TGTC_MX_ONE_CHAIN
+#define TGTC_MX_ONE_CHAIN 1
+#endif
+
 namespace tgtc {
 
 typedef unsigned u6v __attribute__((ext_vector_type(6)));
@@ -251,8 +258,8 @@ __device__ __forceinline__ void mx_store_act(const float4v& acc, MxAct<NKB>& y, 
 // One dense layer.  Groups Q0 + rt*(NKB + (NPE>0)) + i.  X: activation operands (NKB blocks), Ph/Pl: the NPE
 // fp16 hi/lo k-steps (encodings).  epi(ic<rt>, ic<half>, acc) as in dense_layer, NCT = 1.
 // rs_lane: LDS address of the row-exponent table + 2*(lane&15) (u16: byte 0 = Wh6 exponent, byte 1 = Wl6's).
-// Two accumulator chains per row tile -- main (bias + fp16 products) and corr (fp6 products), summed in the
-// epilogue -- so that consecutive MFMAs are not all dependent on each other.  The instruction order is pinned
+// One accumulator chain per row tile (TGTC_MX_ONE_CHAIN; round 1 kept the fp6 products in a second accumulator and
+// summed the two in the epilogue: four moves and four adds per row tile more, no faster).  The instruction order is pinned
 // step by step (sched_barrier): one MFMA, the refill reads of the unit it consumed, a slice of VALU work.
 struct MxNoTrace {
     template <int I>
@@ -266,6 +273,7 @@ __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cpt
     typedef __attribute__((address_space(3))) const float4v* lds_f4;
     typedef __attribute__((address_space(3))) const unsigned short* lds_u16;
     float4v accm[2], accc[2];
+    constexpr bool ONE = TGTC_MX_ONE_CHAIN && NKB > 0;
     int rs[2] = {0, 0};
     accm[0] = *(lds_f4)(bias_lane + BIAS0 * 4);
     if constexpr (NKB > 0) rs[0] = *(lds_u16)(rs_lane + BIAS0 * 2);
@@ -273,7 +281,7 @@ __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cpt
     static_for<RT>([&](auto rt_) {
         constexpr int rt = decltype(rt_)::value;
         constexpr int cur = rt & 1;
-        if constexpr (NKB > 0) accc[cur] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (NKB > 0 && !ONE) accc[cur] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
         static_for<GPR>([&](auto gi_) {
             constexpr int gi = decltype(gi_)::value;
             constexpr int Q = Q0 + rt * GPR + gi;
@@ -282,7 +290,7 @@ __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cpt
             auto deferred = [&] {
                 if constexpr (rt > 0) {
                     float4v sum = accm[cur ^ 1];
-                    if constexpr (NKB > 0) sum += accc[cur ^ 1];
+                    if constexpr (NKB > 0 && !ONE) sum += accc[cur ^ 1];
                     if constexpr (GPR == 1) {
                         epi(ic<rt - 1>{}, ic<0>{}, sum);
                         epi(ic<rt - 1>{}, ic<1>{}, sum);
@@ -302,7 +310,8 @@ __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cpt
                 accm[cur] = mfma16(rd.u[0], X.h[4 * kb + 0], accm[cur]);
                 rd.template refill<Q + 1, NQ, 0>();
                 fence();
-                accc[cur] = mfma_fp6<1, 0>(rd.w6[0], X.h6[kb], accc[cur], rs[cur], X.sc[kb]);
+                if constexpr (ONE) accm[cur] = mfma_fp6<1, 0>(rd.w6[0], X.h6[kb], accm[cur], rs[cur], X.sc[kb]);
+                else accc[cur] = mfma_fp6<1, 0>(rd.w6[0], X.h6[kb], accc[cur], rs[cur], X.sc[kb]);
                 rd.template refill<Q + 1, NQ, 4>();
                 rd.template refill<Q + 1, NQ, 6>();
                 fence();
@@ -313,7 +322,8 @@ __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cpt
                 accm[cur] = mfma16(rd.u[2], X.h[4 * kb + 2], accm[cur]);
                 rd.template refill<Q + 1, NQ, 2>();
                 fence();
-                accc[cur] = mfma_fp6<0, 1>(rd.w6[1], X.l6[kb], accc[cur], rs[cur], X.sc[kb]);
+                if constexpr (ONE) accm[cur] = mfma_fp6<0, 1>(rd.w6[1], X.l6[kb], accm[cur], rs[cur], X.sc[kb]);
+                else accc[cur] = mfma_fp6<0, 1>(rd.w6[1], X.l6[kb], accc[cur], rs[cur], X.sc[kb]);
                 rd.template refill<Q + 1, NQ, 5>();
                 rd.template refill<Q + 1, NQ, 7>();
                 fence();
@@ -324,7 +334,7 @@ __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cpt
                 static_for<NPE>([&](auto k_) {
                     constexpr int k = decltype(k_)::value;
                     accm[cur] = mfma16(rd.u[2 * k], Ph[k], accm[cur]);
-                    if constexpr (NKB > 0) accc[cur] = mfma16(rd.u[2 * k + 1], Ph[k], accc[cur]);
+                    if constexpr (NKB > 0 && !ONE) accc[cur] = mfma16(rd.u[2 * k + 1], Ph[k], accc[cur]);
                     else accm[cur] = mfma16(rd.u[2 * k + 1], Ph[k], accm[cur]);
                     accm[cur] = mfma16(rd.u[2 * k], Pl[k], accm[cur]);
                     rd.template refill<Q + 1, NQ, 2 * k>();
@@ -341,7 +351,9 @@ __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cpt
     // 4-pass MFMA; on gfx950 hardware that is not enough (stale accumulators were read right behind the last fp6
     // MFMA of a layer).  The deferred epilogues are >= 6 MFMAs behind; only this final one needs the explicit drain.
     float4v sum = accm[(RT - 1) & 1];
-    if constexpr (NKB > 0) {
+    if constexpr (ONE) {
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sum));
+    } else if constexpr (NKB > 0) {
         asm volatile("s_nop 7\n\ts_nop 7" : "+v"(accc[(RT - 1) & 1]));
         sum += accc[(RT - 1) & 1];
     }
