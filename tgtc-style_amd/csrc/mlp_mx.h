@@ -24,6 +24,9 @@
 // 1: the fp6 correction products accumulate into the row tile's main accumulator (one dependent chain; the two waves of
 // a SIMD cover each other's MFMA latency); 0: a separate correction accumulator summed in the epilogue (round 1).
 // Measured 101.5 -> 100.2 ms on the headline frame (profiles/r2_kernel_variants.md section 13).
+#ifndef TGTC_MX_DEPTH
+#define TGTC_MX_DEPTH 1
+#endif
 #ifndef TGTC_MX_ONE_CHAIN
 #define TGTC_MX_ONE_CHAIN 1
 #endif
@@ -98,16 +101,17 @@ __host__ __device__ inline float e2m3_value(int code) {
 // activations resident) has no room for a second group buffer, so the NEXT group's units are read into the
 // registers of the current group as soon as the MFMA that consumed each of them has issued (refill<>), and the
 // single lgkmcnt(0) the compiler emits lands at the start of the next group (acquire<>).
-template <class C, class Map, const MxTable& T, bool PERSIST = false>
+template <class C, class Map, const MxTable& T, bool PERSIST = false, int DEPTH_ = TGTC_MX_DEPTH>
 struct MxReader {
+    static constexpr int DEPTH = DEPTH_;   // groups staged ahead of the one being multiplied (1 or 2 register buffers)
     using Ring = WeightStream<C, Map, PERSIST, true>;   // counted LDS waits need the DMA hidden in asm (mlp_core.h)
     Ring ring;
     __device__ __forceinline__ static const char* lane_src(const char* stream, int wave, int lane) {
         return Ring::lane_src(stream, wave, lane);
     }
     lds_cptr b8_lo, b8_hi;  // ring + lane*8, lower / upper 64 KiB
-    half8 u[4];             // units 0..3: fp16 fragments (K group: Wh k-steps; P group: hi/lo pairs)
-    u6v w6[2];              // K group: Wl6 (units 4 = dwords 0-3, 6 = dwords 4-5), Wh6 (units 5, 7)
+    half8 ub[DEPTH][4];     // [group % DEPTH] units 0..3: fp16 fragments (K group: Wh k-steps; P group: hi/lo pairs)
+    u6v wb[DEPTH][2];       // K group: Wl6 (units 4 = dwords 0-3, 6 = dwords 4-5), Wh6 (units 5, 7)
 
     __device__ __forceinline__ void init(const char* const (&streams)[Map::NSEG], char* smem, int wave, int lane) {
         ring.init(streams, smem, wave, lane);
@@ -137,13 +141,15 @@ struct MxReader {
         if constexpr (Q < NQ) {
             if constexpr (J < units(Q)) {
                 if constexpr (J < 4) {
-                    u[J] = read16<T.off[Q] + 1024 * J>();
+                    ub[Q % DEPTH][J] = read16<T.off[Q] + 1024 * J>();
                 } else if constexpr (J < 6) {
                     const u4v t = __builtin_bit_cast(u4v, read16<T.off[Q] + 1024 * J>());
-                    w6[J - 4][0] = t[0], w6[J - 4][1] = t[1], w6[J - 4][2] = t[2], w6[J - 4][3] = t[3];
+                    u6v& w = wb[Q % DEPTH][J - 4];
+                    w[0] = t[0], w[1] = t[1], w[2] = t[2], w[3] = t[3];
                 } else {
                     const u2v t = read8<T.off[Q] + 6144 + 512 * (J - 6)>();
-                    w6[J - 6][4] = t[0], w6[J - 6][5] = t[1];
+                    u6v& w = wb[Q % DEPTH][J - 6];
+                    w[4] = t[0], w[5] = t[1];
                 }
             }
         }
@@ -156,18 +162,18 @@ struct MxReader {
     // ring prologue was issued by the caller (ring.prologue()); wait for chunks 0,1 and read group Q0
     template <int Q0, int NQ>
     __device__ __forceinline__ void start() {
-        static_assert(chunk_hi(Q0) <= 1, "first group must lie in chunks 0..1");
+        static_assert(chunk_hi(Q0 + DEPTH - 1) <= 1, "the first groups must lie in chunks 0..1");
         ring.start_ring();
-        refill_from<Q0, NQ, 0>();
+        static_for<DEPTH>([&](auto d) { refill_from<Q0 + decltype(d)::value, NQ, 0>(); });
         __builtin_amdgcn_sched_barrier(0);
     }
     // PERSIST (fused ray kernel): enter the stream ring.next points to and read group Q0; finish<NQ>() walks the ring
     // to the end of the padded pass (WeightStream, PERSIST): acquire<> has entered chunks up to chunk_hi(NQ-1) - 1.
     template <int Q0, int NQ>
     __device__ __forceinline__ void enter() {
-        static_assert(chunk_hi(Q0) <= 1, "first group must lie in chunks 0..1");
+        static_assert(chunk_hi(Q0 + DEPTH - 1) <= 1, "the first groups must lie in chunks 0..1");
         ring.enter_ring();
-        refill_from<Q0, NQ, 0>();
+        static_for<DEPTH>([&](auto d) { refill_from<Q0 + decltype(d)::value, NQ, 0>(); });
         __builtin_amdgcn_sched_barrier(0);
     }
     template <int NQ>
@@ -180,17 +186,31 @@ struct MxReader {
     // barrier (volatile asm statements and the barrier keep their order).  With groups of at most half a chunk the
     // case cannot arise (group Q+1 would have to cover a whole chunk), so today this compiles to nothing; it guards
     // the invariant should the group or chunk size change.
+    // the last chunk that must have been entered so that group q + DEPTH (the one refilled while group q runs) is readable
+    static constexpr int last_needed(int q, int nq) {
+        const int g = q + DEPTH < nq - 1 ? q + DEPTH : nq - 1;
+        return chunk_hi(g) - 1;
+    }
+    // make the reads of staged group G complete if its bytes reach back into chunk HI-1 (whose slot is about to be re-filled)
+    template <int G, int HI, int NQ>
+    __device__ __forceinline__ void retire() {
+        if constexpr (G < NQ) {
+            if constexpr (T.off[G] / kChunkBytes < HI) {
+                static_for<(units(G) < 4 ? units(G) : 4)>([&](auto j) { asm volatile("" ::"v"(ub[G % DEPTH][decltype(j)::value])); });
+                if constexpr (units(G) == 8) asm volatile("" ::"v"(wb[G % DEPTH][0]), "v"(wb[G % DEPTH][1]));
+            }
+        }
+    }
     template <int Q, int NQ>
     __device__ __forceinline__ void acquire() {
-        if constexpr (Q + 1 < NQ) {
-            constexpr int c0 = chunk_hi(Q) > 1 ? chunk_hi(Q) : 1, c1 = chunk_hi(Q + 1) - 1;
-            if constexpr (c1 >= c0) {
-                if constexpr (T.off[Q] / kChunkBytes < c0) {
-                    static_for<(units(Q) < 4 ? units(Q) : 4)>([&](auto j) { asm volatile("" ::"v"(u[decltype(j)::value])); });
-                    if constexpr (units(Q) == 8) asm volatile("" ::"v"(w6[0]), "v"(w6[1]));
-                }
-                static_for<c1 - c0 + 1>([&](auto i) { ring.template boundary<c0 + decltype(i)::value>(); });
-            }
+        constexpr int prev = Q == 0 ? 0 : last_needed(Q - 1, NQ);
+        constexpr int lo = prev + 1 > 1 ? prev + 1 : 1, hi = last_needed(Q, NQ);
+        if constexpr (hi >= lo) {
+            // boundary<hi> re-fills the slot of chunk hi-1: groups already staged in registers whose bytes reach back into
+            // it must have their reads retired first
+            retire<Q, hi, NQ>();
+            if constexpr (DEPTH > 1) retire<Q + 1, hi, NQ>();
+            static_for<hi - lo + 1>([&](auto i) { ring.template boundary<lo + decltype(i)::value>(); });
         }
     }
 };
@@ -305,43 +325,46 @@ __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cpt
             };
             rd.template acquire<Q, NQ>();
             trace(ic<rt * GPR + gi>{});
+            constexpr int D = Reader::DEPTH;
+            half8 (&U)[4] = rd.ub[Q % D];
+            u6v (&W)[2] = rd.wb[Q % D];
             if constexpr (gi < NKB) {
                 constexpr int kb = gi;
-                accm[cur] = mfma16(rd.u[0], X.h[4 * kb + 0], accm[cur]);
-                rd.template refill<Q + 1, NQ, 0>();
+                accm[cur] = mfma16(U[0], X.h[4 * kb + 0], accm[cur]);
+                rd.template refill<Q + D, NQ, 0>();
                 fence();
-                if constexpr (ONE) accm[cur] = mfma_fp6<1, 0>(rd.w6[0], X.h6[kb], accm[cur], rs[cur], X.sc[kb]);
-                else accc[cur] = mfma_fp6<1, 0>(rd.w6[0], X.h6[kb], accc[cur], rs[cur], X.sc[kb]);
-                rd.template refill<Q + 1, NQ, 4>();
-                rd.template refill<Q + 1, NQ, 6>();
+                if constexpr (ONE) accm[cur] = mfma_fp6<1, 0>(W[0], X.h6[kb], accm[cur], rs[cur], X.sc[kb]);
+                else accc[cur] = mfma_fp6<1, 0>(W[0], X.h6[kb], accc[cur], rs[cur], X.sc[kb]);
+                rd.template refill<Q + D, NQ, 4>();
+                rd.template refill<Q + D, NQ, 6>();
                 fence();
-                accm[cur] = mfma16(rd.u[1], X.h[4 * kb + 1], accm[cur]);
-                rd.template refill<Q + 1, NQ, 1>();
+                accm[cur] = mfma16(U[1], X.h[4 * kb + 1], accm[cur]);
+                rd.template refill<Q + D, NQ, 1>();
                 deferred();  // early in the group: the bias / row-exponent reads it ends with are needed at the next row tile's start
                 fence();
-                accm[cur] = mfma16(rd.u[2], X.h[4 * kb + 2], accm[cur]);
-                rd.template refill<Q + 1, NQ, 2>();
+                accm[cur] = mfma16(U[2], X.h[4 * kb + 2], accm[cur]);
+                rd.template refill<Q + D, NQ, 2>();
                 fence();
-                if constexpr (ONE) accm[cur] = mfma_fp6<0, 1>(rd.w6[1], X.l6[kb], accm[cur], rs[cur], X.sc[kb]);
-                else accc[cur] = mfma_fp6<0, 1>(rd.w6[1], X.l6[kb], accc[cur], rs[cur], X.sc[kb]);
-                rd.template refill<Q + 1, NQ, 5>();
-                rd.template refill<Q + 1, NQ, 7>();
+                if constexpr (ONE) accm[cur] = mfma_fp6<0, 1>(W[1], X.l6[kb], accm[cur], rs[cur], X.sc[kb]);
+                else accc[cur] = mfma_fp6<0, 1>(W[1], X.l6[kb], accc[cur], rs[cur], X.sc[kb]);
+                rd.template refill<Q + D, NQ, 5>();
+                rd.template refill<Q + D, NQ, 7>();
                 fence();
-                accm[cur] = mfma16(rd.u[3], X.h[4 * kb + 3], accm[cur]);
-                rd.template refill<Q + 1, NQ, 3>();
+                accm[cur] = mfma16(U[3], X.h[4 * kb + 3], accm[cur]);
+                rd.template refill<Q + D, NQ, 3>();
                 fence();
             } else {
                 static_for<NPE>([&](auto k_) {
                     constexpr int k = decltype(k_)::value;
-                    accm[cur] = mfma16(rd.u[2 * k], Ph[k], accm[cur]);
-                    if constexpr (NKB > 0 && !ONE) accc[cur] = mfma16(rd.u[2 * k + 1], Ph[k], accc[cur]);
-                    else accm[cur] = mfma16(rd.u[2 * k + 1], Ph[k], accm[cur]);
-                    accm[cur] = mfma16(rd.u[2 * k], Pl[k], accm[cur]);
-                    rd.template refill<Q + 1, NQ, 2 * k>();
-                    rd.template refill<Q + 1, NQ, 2 * k + 1>();
+                    accm[cur] = mfma16(U[2 * k], Ph[k], accm[cur]);
+                    if constexpr (NKB > 0 && !ONE) accc[cur] = mfma16(U[2 * k + 1], Ph[k], accc[cur]);
+                    else accm[cur] = mfma16(U[2 * k + 1], Ph[k], accm[cur]);
+                    accm[cur] = mfma16(U[2 * k], Pl[k], accm[cur]);
+                    rd.template refill<Q + D, NQ, 2 * k>();
+                    rd.template refill<Q + D, NQ, 2 * k + 1>();
                     fence();
                 });
-                rd.template refill_from<Q + 1, NQ, 2 * NPE>();
+                rd.template refill_from<Q + D, NQ, 2 * NPE>();
                 deferred();
                 fence();
             }
@@ -359,172 +382,6 @@ __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cpt
     }
     epi(ic<RT - 1>{}, ic<0>{}, sum);
     epi(ic<RT - 1>{}, ic<1>{}, sum);
-}
-
-// ================================================================================================ PARK geometry
-// One wave per SIMD (4 waves, 512 registers), NCT column tiles per wave: every weight group read from LDS feeds
-// NCT x 6 MFMAs (the 8-wave kernel above reads 7 KiB per 6 MFMAs and is bound by that), the layer being produced is
-// parked in AGPRs (mlp_core.h park / unpark) and every MFMA operand is an architectural VGPR.
-template <int NKB>
-struct MxParked {
-    unsigned h[4 * NKB][4];
-    unsigned h6[NKB][6], l6[NKB][6];
-    unsigned sc[NKB];
-    unsigned mxk;  // (VGPR) packed running maximum of the block being produced
-};
-
-template <int NKB>
-__device__ __forceinline__ void mx_unpark(const MxParked<NKB>& p, MxAct<NKB>& x) {
-#pragma unroll
-    for (int k = 0; k < 4 * NKB; ++k) x.h[k] = unpark4(p.h[k]);
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) x.h6[kb][i] = unpark(p.h6[kb][i]), x.l6[kb][i] = unpark(p.l6[kb][i]);
-        x.sc[kb] = (int)unpark(p.sc[kb]);
-    }
-}
-
-// ReLU + split of one HALF of row tile RT's accumulator (one column tile); the hi pair is parked at once, the lo
-// pair (scaled by 2^11) waits in l16 until its 128-feature block closes and both become fp6.
-template <int RT, int HALF, int NKB>
-__device__ __forceinline__ void mx_store_act_p(const float4v& acc, MxParked<NKB>& y, half8 (&l16)[4]) {
-    constexpr int ks = RT / 2, e0 = (RT & 1) * 4 + 2 * HALF;
-    unsigned hpk, lpk;
-    split_pair(acc[2 * HALF], acc[2 * HALF + 1], hpk, lpk);
-    set_pair(l16[ks & 3], e0, lpk);
-    y.mxk = ((RT & 7) == 0 && HALF == 0) ? hpk : pk_max_u16(y.mxk, hpk);
-    y.h[ks][(RT & 1) * 2 + HALF] = park(hpk);
-    if constexpr ((RT & 7) == 7 && HALF == 1) {
-        constexpr int kb = RT / 8;
-        const int byte_h = block_exp_byte(y.mxk);
-        const u6v c_h = cvt_fp6(unpark4(y.h[4 * kb]), unpark4(y.h[4 * kb + 1]), unpark4(y.h[4 * kb + 2]), unpark4(y.h[4 * kb + 3]),
-                                __builtin_bit_cast(float, byte_h << 23));
-        const u6v c_l = cvt_fp6(l16[0], l16[1], l16[2], l16[3], __builtin_bit_cast(float, (byte_h - 11) << 23));
-#pragma unroll
-        for (int i = 0; i < 6; ++i) y.h6[kb][i] = park(c_h[i]), y.l6[kb][i] = park(c_l[i]);
-        y.sc[kb] = park((unsigned)(byte_h | ((byte_h - 11) << 8)));
-    }
-}
-
-// One dense layer for NCT column tiles.  Same stream, same arithmetic per column tile as dense_mx.  A row tile's
-// groups are walked unit by unit (a unit = one LDS->register burst = one MFMA per column tile); the 2*NCT epilogue
-// units of the PREVIOUS row tile are spread over the steps of this one, the first of them three steps in (at least
-// 3*NCT MFMAs behind the fp6 MFMA whose result they read, see the hazard note in dense_mx).
-// epi(ic<rt>, ic<c>, ic<half>, sum).
-template <class C, int Q0, int NQ, int RT, int NKB, int NPE, int BIAS0, class Reader, class Epi>
-__device__ __forceinline__ void dense_mx_p(Reader& rd, lds_cptr bias_lane, lds_cptr rs_lane,
-                                           const MxAct<(NKB ? NKB : 1)> (&X)[C::NCT], const half8 (&Ph)[NPE ? NPE : 1][C::NCT],
-                                           const half8 (&Pl)[NPE ? NPE : 1][C::NCT], Epi&& epi) {
-    constexpr int NCT = C::NCT;
-    constexpr int GPR = NKB + (NPE ? 1 : 0);
-    constexpr int STEPS = 6 * NKB + NPE;   // per row tile
-    constexpr int UNITS = 2 * NCT;
-    constexpr int FIRST = STEPS > 3 ? 2 : 0;                       // first step that carries an epilogue unit
-    constexpr int SPAN = STEPS - FIRST;
-    typedef __attribute__((address_space(3))) const float4v* lds_f4;
-    typedef __attribute__((address_space(3))) const unsigned short* lds_u16;
-    float4v accm[2][NCT], accc[2][NCT];
-    float4v bias[2];
-    int rs[2] = {0, 0};
-    bias[0] = *(lds_f4)(bias_lane + BIAS0 * 4);
-    if constexpr (NKB > 0) rs[0] = *(lds_u16)(rs_lane + BIAS0 * 2);
-    auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
-    static_for<RT>([&](auto rt_) {
-        constexpr int rt = decltype(rt_)::value;
-        constexpr int cur = rt & 1;
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-            accm[cur][c] = bias[cur];
-            if constexpr (NKB > 0) accc[cur][c] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-        // epilogue units of row tile rt-1 that belong behind step `st` of this row tile
-        auto slice = [&](auto st_) {
-            constexpr int st = decltype(st_)::value;
-            if constexpr (rt > 0) {
-                static_for<UNITS>([&](auto u_) {
-                    constexpr int u = decltype(u_)::value;
-                    constexpr int at = FIRST + (u * SPAN) / UNITS;
-                    if constexpr (at == st) {
-                        constexpr int c = u / 2, hf = u % 2;
-                        float4v sum = accm[cur ^ 1][c];
-                        if constexpr (NKB > 0) sum += accc[cur ^ 1][c];
-                        epi(ic<rt - 1>{}, ic<c>{}, ic<hf>{}, sum);
-                    }
-                });
-            }
-            if constexpr (st == 1 && rt + 1 < RT) {   // next row tile's bias and weight exponents, one row tile ahead
-                bias[cur ^ 1] = *(lds_f4)(bias_lane + (BIAS0 + 16 * (rt + 1)) * 4);
-                if constexpr (NKB > 0) rs[cur ^ 1] = *(lds_u16)(rs_lane + (BIAS0 + 16 * (rt + 1)) * 2);
-            }
-        };
-        static_for<GPR>([&](auto gi_) {
-            constexpr int gi = decltype(gi_)::value;
-            constexpr int Q = Q0 + rt * GPR + gi;
-            rd.template acquire<Q, NQ>();
-            if constexpr (gi < NKB) {
-                constexpr int kb = gi, s0 = 6 * gi;
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) accm[cur][c] = mfma16(rd.u[0], X[c].h[4 * kb + 0], accm[cur][c]);
-                rd.template refill<Q + 1, NQ, 0>();
-                slice(ic<s0 + 0>{});
-                fence();
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) accc[cur][c] = mfma_fp6<1, 0>(rd.w6[0], X[c].h6[kb], accc[cur][c], rs[cur], X[c].sc[kb]);
-                rd.template refill<Q + 1, NQ, 4>();
-                rd.template refill<Q + 1, NQ, 6>();
-                slice(ic<s0 + 1>{});
-                fence();
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) accm[cur][c] = mfma16(rd.u[1], X[c].h[4 * kb + 1], accm[cur][c]);
-                rd.template refill<Q + 1, NQ, 1>();
-                slice(ic<s0 + 2>{});
-                fence();
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) accm[cur][c] = mfma16(rd.u[2], X[c].h[4 * kb + 2], accm[cur][c]);
-                rd.template refill<Q + 1, NQ, 2>();
-                slice(ic<s0 + 3>{});
-                fence();
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) accc[cur][c] = mfma_fp6<0, 1>(rd.w6[1], X[c].l6[kb], accc[cur][c], rs[cur], X[c].sc[kb]);
-                rd.template refill<Q + 1, NQ, 5>();
-                rd.template refill<Q + 1, NQ, 7>();
-                slice(ic<s0 + 4>{});
-                fence();
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) accm[cur][c] = mfma16(rd.u[3], X[c].h[4 * kb + 3], accm[cur][c]);
-                rd.template refill<Q + 1, NQ, 3>();
-                slice(ic<s0 + 5>{});
-                fence();
-            } else {
-                static_for<NPE>([&](auto k_) {
-                    constexpr int k = decltype(k_)::value;
-#pragma unroll
-                    for (int c = 0; c < NCT; ++c) {
-                        accm[cur][c] = mfma16(rd.u[2 * k], Ph[k][c], accm[cur][c]);
-                        if constexpr (NKB > 0) accc[cur][c] = mfma16(rd.u[2 * k + 1], Ph[k][c], accc[cur][c]);
-                        else accm[cur][c] = mfma16(rd.u[2 * k + 1], Ph[k][c], accm[cur][c]);
-                        accm[cur][c] = mfma16(rd.u[2 * k], Pl[k][c], accm[cur][c]);
-                    }
-                    rd.template refill<Q + 1, NQ, 2 * k>();
-                    rd.template refill<Q + 1, NQ, 2 * k + 1>();
-                    if constexpr (k == NPE - 1) rd.template refill_from<Q + 1, NQ, 2 * NPE>();
-                    slice(ic<6 * NKB + k>{});
-                    fence();
-                });
-            }
-        });
-    });
-    static_for<NCT>([&](auto c_) {
-        constexpr int c = decltype(c_)::value;
-        float4v sum = accm[(RT - 1) & 1][c];
-        if constexpr (NKB > 0) {
-            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(accc[(RT - 1) & 1][c]));
-            sum += accc[(RT - 1) & 1][c];
-        }
-        epi(ic<RT - 1>{}, ic<c>{}, ic<0>{}, sum);
-        epi(ic<RT - 1>{}, ic<c>{}, ic<1>{}, sum);
-    });
 }
 
 }  // namespace tgtc

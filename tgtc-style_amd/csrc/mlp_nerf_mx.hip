@@ -76,138 +76,7 @@ __global__ void __launch_bounds__(512, 2) nerf_mx_kernel(NerfArgs a) {
         });
 }
 
-#ifndef TGTC_MX_PARK
-#define TGTC_MX_PARK 0   // experimental geometry, measured slower (profiles/r2_kernel_variants.md); not built by default
-#endif
-#if TGTC_MX_PARK
-// ------------------------------------------------------------------------------------------------ PARK geometry
-// 4 waves (one per SIMD, 512 registers) x 2 column tiles: 128 samples per workgroup like the 8-wave kernel, but each
-// weight group is read from LDS by 4 waves instead of 8 and feeds 12 MFMAs instead of 6 (mlp_mx.h, dense_mx_p).
-using CfgMxP = MlpCfg<4, 2, false, 4, kRingSlots, 1, true>;
 
-template <int IN_MODE, bool FULL>
-__global__ void __launch_bounds__(256, 1) nerf_mx_kernel_p(NerfArgs a) {
-    using C = CfgMxP;
-    using L = NerfLayout;
-    constexpr int NCT = C::NCT;
-    constexpr int NQ = FULL ? kNerfMxTable.first[12] : kNerfMxTable.first[9];
-    constexpr int NUNITS = mx_bytes_upto(kNerfMxTable, NQ) / 1024;
-    __shared__ __attribute__((aligned(16))) char smem[C::RING_BYTES + kNerfBiasBytes];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = lane >> 4, n = lane & 15;
-    const long long s_wave = (long long)blockIdx.x * C::SAMPLES_PER_WG + wave * C::SAMPLES_PER_WAVE;
-
-    double pos[NCT][3], dir[NCT][3];
-    long long sidx[NCT];
-    nerf_load_samples<NCT, IN_MODE>(a, s_wave, n, pos, dir, sidx);
-    half8 pe_h[2][NCT], pe_l[2][NCT], de_h[1][NCT], de_l[1][NCT];
-    if constexpr (IN_MODE == IN_ENC) nerf_load_encoded<NCT, true, false>(a, sidx, g, pe_h, pe_l, de_h, de_l);
-
-    MxReader<C, SingleStreamMap<NUNITS>, kNerfMxTable> rd;
-    const char* const streams[1] = {a.stream};
-    rd.init(streams, smem, wave, lane);
-#pragma unroll
-    for (int j = 0; j < kNerfBiasBytes / (C::NWAVES * 1024); ++j)
-        lds_dma16(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16, smem + C::RING_BYTES + (j * C::NWAVES + wave) * 1024);
-    rd.ring.prologue();
-    if constexpr (IN_MODE != IN_ENC) nerf_encode<NCT, true, false>(a, pos, dir, sidx, g, pe_h, pe_l, de_h, de_l);
-
-    const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * g);
-    const lds_cptr rs_lane = opaque((lds_cptr)smem + C::RING_BYTES + kNerfMxScaleOff + 2 * n);
-    rd.template start<0, NQ>();
-
-    MxAct<2> X[NCT];
-    MxParked<2> P[NCT];
-    MxAct<1> none[NCT];
-    half8 l16[NCT][4];
-    half8 nop[1][NCT];
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) nop[0][c] = half8{};
-    auto to_P = [&](auto rt_, auto c_, auto h_, const float4v& acc) {
-        constexpr int c = decltype(c_)::value;
-        mx_store_act_p<decltype(rt_)::value, decltype(h_)::value>(acc, P[c], l16[c]);
-    };
-    auto flip = [&] {
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) mx_unpark(P[c], X[c]);
-    };
-    constexpr const MxTable& T = kNerfMxTable;
-
-    dense_mx_p<C, T.first[0], NQ, 16, 0, 2, L::bias0(0)>(rd, bias_lane, rs_lane, none, pe_h, pe_l, to_P);
-    // the point encoding is needed again by the skip layer only: park it meanwhile
-    unsigned pk_h[2][NCT][4], pk_l[2][NCT][4];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) park4(pe_h[k][c], pk_h[k][c]), park4(pe_l[k][c], pk_l[k][c]);
-    flip();
-    dense_mx_p<C, T.first[1], NQ, 16, 2, 0, L::bias0(1)>(rd, bias_lane, rs_lane, X, nop, nop, to_P);
-    flip();
-    dense_mx_p<C, T.first[2], NQ, 16, 2, 0, L::bias0(2)>(rd, bias_lane, rs_lane, X, nop, nop, to_P);
-    flip();
-    dense_mx_p<C, T.first[3], NQ, 16, 2, 0, L::bias0(3)>(rd, bias_lane, rs_lane, X, nop, nop, to_P);
-    flip();
-    dense_mx_p<C, T.first[4], NQ, 16, 2, 0, L::bias0(4)>(rd, bias_lane, rs_lane, X, nop, nop, to_P);
-    flip();
-    {
-        // skip layer: reference input is cat(pe, h) (models.py:98-99); k order here is [h | pe]
-        half8 Sh[2][NCT], Sl[2][NCT];
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) Sh[k][c] = unpark4(pk_h[k][c]), Sl[k][c] = unpark4(pk_l[k][c]);
-        dense_mx_p<C, T.first[5], NQ, 16, 2, 2, L::bias0(5)>(rd, bias_lane, rs_lane, X, Sh, Sl, to_P);
-    }
-    flip();
-    dense_mx_p<C, T.first[6], NQ, 16, 2, 0, L::bias0(6)>(rd, bias_lane, rs_lane, X, nop, nop, to_P);
-    flip();
-    dense_mx_p<C, T.first[7], NQ, 16, 2, 0, L::bias0(7)>(rd, bias_lane, rs_lane, X, nop, nop, to_P);
-    flip();
-
-    // sigma head (models.py:103): row 0 of a 16-row tile -> lanes 0..15, register 0
-    dense_mx_p<C, T.first[8], NQ, 1, 2, 0, L::bias0(8)>(rd, bias_lane, rs_lane, X, nop, nop, [&](auto, auto c_, auto h_, const float4v& acc) {
-        constexpr int c = decltype(c_)::value;
-        if constexpr (decltype(h_)::value == 0)
-            if (g == 0 && a.sigma && sidx[c] < a.M) a.sigma[sidx[c]] = acc[0];
-    });
-
-    if constexpr (FULL) {
-        // base_remap (models.py:106) and the colour head (models.py:107-111)
-        dense_mx_p<C, T.first[9], NQ, 16, 2, 0, L::bias0(9)>(rd, bias_lane, rs_lane, X, nop, nop, [&](auto rt_, auto c_, auto h_, const float4v& acc) {
-            constexpr int rt = decltype(rt_)::value, c = decltype(c_)::value, hf = decltype(h_)::value;
-            mx_store_act_p<rt, hf>(acc, P[c], l16[c]);
-            if (a.remap && sidx[c] < a.M) {
-                float* o = a.remap + sidx[c] * 256 + 16 * rt + 4 * g + 2 * hf;
-                o[0] = relu(acc[2 * hf]), o[1] = relu(acc[2 * hf + 1]);
-            }
-        });
-        flip();
-        half8 Dh[1][NCT], Dl[1][NCT];
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-            nerf_encode_dir_late<IN_MODE, true>(a, sidx[c], g, de_h[0][c], de_l[0][c]);
-            Dh[0][c] = de_h[0][c], Dl[0][c] = de_l[0][c];
-        }
-        MxParked<1> PZ[NCT];
-        dense_mx_p<C, T.first[10], NQ, 8, 2, 1, L::bias0(10)>(rd, bias_lane, rs_lane, X, Dh, Dl, [&](auto rt_, auto c_, auto h_, const float4v& acc) {
-            constexpr int c = decltype(c_)::value;
-            mx_store_act_p<decltype(rt_)::value, decltype(h_)::value>(acc, PZ[c], l16[c]);
-        });
-        MxAct<1> Z[NCT];
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) mx_unpark(PZ[c], Z[c]);
-        dense_mx_p<C, T.first[11], NQ, 1, 1, 0, L::bias0(11)>(rd, bias_lane, rs_lane, Z, nop, nop, [&](auto, auto c_, auto h_, const float4v& acc) {
-            constexpr int c = decltype(c_)::value, hf = decltype(h_)::value;
-            if (g == 0 && a.rgb && sidx[c] < a.M) {
-#pragma unroll
-                for (int r = 2 * hf; r < (hf ? 3 : 2); ++r) a.rgb[sidx[c] * 3 + r] = 1.0f / (1.0f + expf(-acc[r]));
-            }
-        });
-    }
-}
-#endif  // TGTC_MX_PARK
 
 // ------------------------------------------------------------------------------------------------ host
 static int e2m3_encode(float x) {
@@ -309,22 +178,6 @@ int nerf_mx_pack(const tgtc_linear* layers, std::vector<char>& bias_region, std:
 }
 
 int nerf_mx_launch(int in_mode, bool full, const NerfArgs& a, hipStream_t st) {
-#if TGTC_MX_PARK
-    {
-        using C = CfgMxP;
-        const unsigned nwg = (unsigned)((a.M + C::SAMPLES_PER_WG - 1) / C::SAMPLES_PER_WG);
-        const dim3 block(C::NWAVES * 64);
-        switch (in_mode * 2 + (full ? 1 : 0)) {
-            case IN_RAYS * 2 + 0: nerf_mx_kernel_p<IN_RAYS, false><<<nwg, block, 0, st>>>(a); break;
-            case IN_RAYS * 2 + 1: nerf_mx_kernel_p<IN_RAYS, true><<<nwg, block, 0, st>>>(a); break;
-            case IN_PTS * 2 + 1: nerf_mx_kernel_p<IN_PTS, true><<<nwg, block, 0, st>>>(a); break;
-            case IN_ENC * 2 + 1: nerf_mx_kernel_p<IN_ENC, true><<<nwg, block, 0, st>>>(a); break;
-            default: return fail(TGTC_ERR_UNSUPPORTED, "nerf (fp16+fp6): no kernel for input mode %d, full %d", in_mode, (int)full);
-        }
-        TGTC_LAUNCH_CHECK();
-        return TGTC_OK;
-    }
-#endif
     using C = CfgMx;
     const unsigned nwg = (unsigned)((a.M + C::SAMPLES_PER_WG - 1) / C::SAMPLES_PER_WG);
     const dim3 block(C::NWAVES * 64);
