@@ -237,3 +237,36 @@ def test_cli_whole_image_batches_equal_literal_batches(tmp_path):
     assert len(names) == 4 and sorted(os.listdir(b)) == names
     for n in names:
         assert open(os.path.join(a, n), "rb").read() == open(os.path.join(b, n), "rb").read(), n
+
+
+def test_cli_geometry_pass_two_ranks(tmp_path):
+    """--render_valid (cal_geometry) under frames sharding: rank r renders and writes frames k = r (mod 2) with their global
+    numbers, rank 0 assembles the scene-wide geometry.npz; every file equals the one-rank run's."""
+    import socket
+    import torch.multiprocessing as mp
+    from tgtc_style_amd import train_tgtcs
+    common = ["--config", os.path.join(ROOT, "configs", "fern.txt"), "--synthetic", "--synthetic_hw", "20", "--synthetic_frames", "3",
+              "--chunk", "1024", "--batch_size", "128", "--render_valid"]
+    one = train_tgtcs.main(common + ["--basedir", str(tmp_path / "one")])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: os.environ.get(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TGTC_DIST_BACKEND")}
+    try:
+        mp.spawn(_cli_rank, args=(2, port, common + ["--basedir", str(tmp_path / "two")], "gloo"), nprocs=2, join=True)
+    finally:
+        for k, v in env.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    two = os.path.join(str(tmp_path / "two"), os.path.relpath(one, str(tmp_path / "one")))
+    names = sorted(os.listdir(one))
+    assert names == sorted(["rgb_%05d.png" % i for i in range(3)] + ["depth_%05d.png" % i for i in range(3)] +
+                           ["geometry_%05d.npz" % i for i in range(3)] + ["geometry.npz"])
+    assert sorted(os.listdir(two)) == names
+    for n in names:
+        if n.endswith(".png"):
+            assert open(os.path.join(one, n), "rb").read() == open(os.path.join(two, n), "rb").read(), n
+        else:
+            a, b = np.load(os.path.join(one, n)), np.load(os.path.join(two, n))
+            assert sorted(a.files) == sorted(b.files)
+            for k in a.files:
+                assert np.array_equal(a[k], b[k]), (n, k)

@@ -163,9 +163,14 @@ def cal_geometry(model_forward, samp_func, dataloader, args, device, sv_path=Non
     cps = ds.cps if train else ds.cps_valid
     frame_num, h, w = (ds.frame_num if train else ds.cps_valid.shape[0]), ds.h, ds.w
     res = h * w
-    rgb_map = np.zeros([frame_num * res, 3], np.float32)
-    t_map = np.zeros([frame_num * res], np.float32)
-    coor_map = np.zeros([frame_num * res, 3], np.float32)
+    # frames sharding (train_tgtcs.ShardedScene): this rank renders the images k with k % world == rank, in that order
+    world, rank = getattr(ds, 'world', 1), getattr(ds, 'rank', 0)
+    if world > 1 and getattr(ds, 'shard', 'frames') != 'frames':
+        raise ValueError("cal_geometry shards by whole frames (--shard frames): geometry_%05d.npz is a per-frame file")
+    local_frames = len(range(rank, frame_num, world)) if world > 1 else frame_num
+    rgb_map = np.zeros([local_frames * res, 3], np.float32)
+    t_map = np.zeros([local_frames * res], np.float32)
+    coor_map = np.zeros([local_frames * res, 3], np.float32)
     img_id = pixel_id = 0
     for batch in dataloader:
         b = _to_device(batch, device)
@@ -191,15 +196,24 @@ def cal_geometry(model_forward, samp_func, dataloader, args, device, sv_path=Non
         if done > 0 and sv_path is not None:
             for i in range(img_id, img_id + done):
                 sl = slice(i * res, (i + 1) * res)
-                _write_depth_rgb(sv_path, rgb_map[sl], t_map[sl], h, w, 'rgb_%05d.png' % i, 'depth_%05d.png' % i)
-                np.savez(os.path.join(sv_path, 'geometry_%05d' % i), coor_map=coor_map[sl].reshape(h, w, 3),
-                         cps=cps[i], hwf=ds.hwf, near=ds.near, far=ds.far)
+                gid = _image_id(ds, i)
+                _write_depth_rgb(sv_path, rgb_map[sl], t_map[sl], h, w, 'rgb_%05d.png' % gid, 'depth_%05d.png' % gid)
+                np.savez(os.path.join(sv_path, 'geometry_%05d' % gid), coor_map=coor_map[sl].reshape(h, w, 3),
+                         cps=cps[gid], hwf=ds.hwf, near=ds.near, far=ds.far)
         img_id += max(done, 0)
     rgb_map, t_map = rgb_map.reshape(-1, h, w, 3), t_map.reshape(-1, h, w, 1)
-    if sv_path is not None:
-        np.savez(os.path.join(sv_path, 'geometry'), coor_map=coor_map.reshape(-1, h, w, 3), cps=cps, hwf=ds.hwf,
-                 near=ds.near, far=ds.far)
     _drain_images()
+    if sv_path is not None:
+        if world > 1:
+            # the scene-wide file: rank 0 puts the per-frame files of all ranks together (one node, one file system)
+            ds.dist.barrier()
+            if rank == 0:
+                whole = np.stack([np.load(os.path.join(sv_path, 'geometry_%05d.npz' % k))['coor_map'] for k in range(frame_num)])
+                np.savez(os.path.join(sv_path, 'geometry'), coor_map=whole, cps=cps, hwf=ds.hwf, near=ds.near, far=ds.far)
+            ds.dist.barrier()
+        else:
+            np.savez(os.path.join(sv_path, 'geometry'), coor_map=coor_map.reshape(-1, h, w, 3), cps=cps, hwf=ds.hwf,
+                     near=ds.near, far=ds.far)
     return rgb_map, t_map
 
 

@@ -190,9 +190,9 @@ def train(args):
                          "of this build, SURVEY section 8f); run with --synthetic for the seeded scene" % args.datadir)
     dataset.jitter_samples = args.N_samples     # per-ray jitter: images independent of --batch_size / --chunk / sharding
     if world > 1:
-        if args.render_valid or args.render_train:
-            raise SystemExit("train_tgtcs: the geometry pass (--render_valid / --render_train) writes one scene-wide "
-                             "geometry.npz and runs on one GPU; the stylised renders shard (--shard frames|rays)")
+        if (args.render_valid or args.render_train) and args.shard != 'frames':
+            raise SystemExit("train_tgtcs: the geometry pass (--render_valid / --render_train) shards by whole frames "
+                             "(--shard frames): geometry_%05d.npz is a per-frame file")
         dataset.set_sharding(rank, world, args.shard, dist)
     # rays per render call: the reference feeds --batch_size rays at a time from its host loader; with device-generated rays
     # a whole image (this rank's part of it) per call keeps the persistent kernels busy -- 78 calls of 2 048 rays cost a
