@@ -16,6 +16,9 @@
 // raymarch_dev.h), so the result of a ray does not depend on which wave, workgroup or launch renders it.
 #include "common.h"
 #include "mlp_core.h"
+#ifndef TGTC_FUSED_X3_ASM_DMA
+#define TGTC_FUSED_X3_ASM_DMA false   // fp16 / fp16x3 passes: builtin LDS-DMA (asm + SGPR-base addressing measured, profiles section 16)
+#endif
 #include "mlp_layouts.h"
 #include "mlp_mx.h"
 #include "mlp_nerf_chain.h"
@@ -60,7 +63,7 @@ struct FusedCfg<TGTC_PREC_FP16_FP6> {
 template <int PREC, bool FULL>
 struct FusedStream {
     using C = typename FusedCfg<PREC>::C;
-    using type = WeightStream<C, SingleStreamMap<(FULL ? NerfLayout::kFragsFull : NerfLayout::kFragsSigma)>, true, false>;
+    using type = WeightStream<C, SingleStreamMap<(FULL ? NerfLayout::kFragsFull : NerfLayout::kFragsSigma)>, true, TGTC_FUSED_X3_ASM_DMA>;
 };
 template <bool FULL>
 struct FusedStream<TGTC_PREC_FP16_FP6, FULL> {
