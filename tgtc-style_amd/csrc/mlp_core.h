@@ -212,8 +212,13 @@ struct WeightStream {
             });
         } else {
             asm volatile("" : "+v"(base));
-#pragma unroll
-            for (int j = 0; j < C::GPC; ++j) lds_dma16_t<false>(base + OFF + j * 1024, lds_wave + SLOT * kChunkBytes + j * 1024);
+            // one 64-bit address per chunk; the 1 KiB steps ride in the instruction's immediate offset, which the hardware
+            // adds to the global address AND to the LDS destination
+            const char* b = base + OFF;
+            static_for<C::GPC>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                __builtin_amdgcn_global_load_lds(TGTC_GPTR(b), TGTC_LPTR(lds_wave + SLOT * kChunkBytes), 16, j * 1024, 0);
+            });
         }
     }
     template <int CH>
