@@ -191,6 +191,17 @@ struct MxReader {
         const int g = q + DEPTH < nq - 1 ? q + DEPTH : nq - 1;
         return chunk_hi(g) - 1;
     }
+    // one counted wait for the whole staged group G (the empty asm "uses" all its units); pays when the group was read two
+    // groups ago (DEPTH 2): the per-MFMA waits hipcc would otherwise emit disappear
+    template <int G, int NQ>
+    __device__ __forceinline__ void touch() {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass instantiates this body through dense_mx's generic lambdas and has no "v" registers)
+        if constexpr (G < NQ) {
+            static_for<(units(G) < 4 ? units(G) : 4)>([&](auto j) { asm volatile("" ::"v"(ub[G % DEPTH][decltype(j)::value])); });
+            if constexpr (units(G) == 8) asm volatile("" ::"v"(wb[G % DEPTH][0]), "v"(wb[G % DEPTH][1]));
+        }
+#endif
+    }
     // make the reads of staged group G complete if its bytes reach back into chunk HI-1 (whose slot is about to be re-filled)
     template <int G, int HI, int NQ>
     __device__ __forceinline__ void retire() {
@@ -326,6 +337,7 @@ __device__ __forceinline__ void dense_mx(Reader& rd, lds_cptr bias_lane, lds_cpt
             rd.template acquire<Q, NQ>();
             trace(ic<rt * GPR + gi>{});
             constexpr int D = Reader::DEPTH;
+            if constexpr (D > 1) rd.template touch<Q, NQ>();
             half8 (&U)[4] = rd.ub[Q % D];
             u6v (&W)[2] = rd.wb[Q % D];
             if constexpr (gi < NKB) {
