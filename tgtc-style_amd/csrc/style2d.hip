@@ -24,14 +24,17 @@ namespace tgtc {
 constexpr int BK = 32, LDK = 40;  // LDK: 32 halves + 8 pad -> 80-byte rows, conflict-free b128 reads
 
 // ------------------------------------------------------------------------------------------------ row loaders
-// load4(ctx, k, v): v[j] = A(row, k + j), zero outside the matrix.  k is a multiple of 4.
+// load4(ctx, k0, kq, v): v[j] = A(row, k0 + kq + j), zero outside the matrix.  k0 is the workgroup-uniform start of the
+// 32-deep k block, kq the thread's quad inside it (a multiple of 4): loaders whose index math has a uniform part (the
+// convolution's tap) can keep it in scalar registers.
 struct DenseRows {  // A(m,k) = p[m*ld + k]
     const float* p;
     long long ld, batch_stride;
     int rows, K;
     struct Ctx { const float* row; };
     __device__ Ctx prep(int m) const { return Ctx{m < rows ? p + (long long)m * ld : nullptr}; }
-    __device__ void load4(const Ctx& c, int k, float (&v)[4]) const {
+    __device__ void load4(const Ctx& c, int k0, int kq, float (&v)[4]) const {
+        const int k = k0 + kq;
         if (c.row && k + 3 < K && ((reinterpret_cast<size_t>(c.row + k) & 15) == 0)) {
             const float4 t = *reinterpret_cast<const float4*>(c.row + k);
             v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
@@ -50,13 +53,17 @@ struct ConvNHWC {  // 3x3, stride 1, ReflectionPad(1); input token-major [Hs*Ws,
     int H, W, Hs, Ws, C, logC, up, rows, K;  // H,W: logical (post-upsample) = output size; k = tap*C + c
     struct Ctx { int y, x; };
     __device__ Ctx prep(int m) const { return m < rows ? Ctx{m / W, m % W} : Ctx{-1, 0}; }
-    __device__ void load4(const Ctx& c, int k, float (&v)[4]) const {
+    __device__ void load4(const Ctx& c, int k0, int kq, float (&v)[4]) const {
+        const int k = k0 + kq;
         if (c.y < 0 || k >= K) {
             v[0] = v[1] = v[2] = v[3] = 0.0f;
             return;
         }
-        const int tap = k >> logC, ch = k & (C - 1);
-        int sy = reflect(c.y + tap / 3 - 1, H), sx = reflect(c.x + tap % 3 - 1, W);
+        // C is a power of two >= 32 (conv3x3 checks): a 32-deep k block lies inside one tap, so the tap and its (dy, dx) are
+        // workgroup-uniform and stay in scalar registers
+        const int tap = k0 >> logC, ch = k & (C - 1);
+        const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+        int sy = reflect(c.y + dy, H), sx = reflect(c.x + dx, W);
         if (up) sy >>= 1, sx >>= 1;
         const float4 t = *reinterpret_cast<const float4*>(p + (((long long)sy * Ws + sx) << logC) + ch);
         v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
@@ -69,7 +76,8 @@ struct ConvSmall {  // ksize x ksize (1 or 3), few input channels, arbitrary inp
     int H, W, C, ksize, rows, K;
     struct Ctx { int y, x; };
     __device__ Ctx prep(int m) const { return m < rows ? Ctx{m / W, m % W} : Ctx{-1, 0}; }
-    __device__ void load4(const Ctx& c, int k, float (&v)[4]) const {
+    __device__ void load4(const Ctx& c, int k0, int kq, float (&v)[4]) const {
+        const int k = k0 + kq;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int kk = k + j;
@@ -91,7 +99,8 @@ struct PatchRows {  // 8x8 stride-8 patches of an NCHW image [3,H,W]; k = c*64 +
     int H, W, wt, rows, K;  // wt = W/8 tokens per row
     struct Ctx { int py, px; };
     __device__ Ctx prep(int m) const { return m < rows ? Ctx{m / wt, m % wt} : Ctx{-1, 0}; }
-    __device__ void load4(const Ctx& c, int k, float (&v)[4]) const {
+    __device__ void load4(const Ctx& c, int k0, int kq, float (&v)[4]) const {
+        const int k = k0 + kq;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int kk = k + j;
@@ -172,9 +181,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
-            al.load4(actx[i], k0 + skq, ra[i]);
+            al.load4(actx[i], k0, skq, ra[i]);
             if constexpr (!B_KMAJOR) {
-                bl.load4(bctx[i], k0 + skq, rb[i]);
+                bl.load4(bctx[i], k0, skq, rb[i]);
             } else {
                 const int k = k0 + bk + 8 * i;
 #pragma unroll
@@ -896,7 +905,7 @@ static int conv3x3(const tgtc_style2d* h, const float* w, const float* b, const 
                    int Cin, int Cout, int relu, float* out, long long sm, long long sn, hipStream_t st) {
     int logC = 0;
     while ((1 << logC) < Cin) ++logC;
-    if ((1 << logC) != Cin || Cin < 4) return fail(TGTC_ERR_UNSUPPORTED, "conv3x3: C_in=%d must be a power of two >= 4", Cin);
+    if ((1 << logC) != Cin || Cin < 32) return fail(TGTC_ERR_UNSUPPORTED, "conv3x3: C_in=%d must be a power of two >= 32", Cin);
     const int H = up ? 2 * Hs : Hs, W = up ? 2 * Ws : Ws, M = H * W, K = 9 * Cin;
     ConvNHWC al{in, 0, H, W, Hs, Ws, Cin, logC, up, M, K};
     DenseRows bl{w, K, 0, Cout, K};
