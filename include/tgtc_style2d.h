@@ -93,6 +93,19 @@ int tgtc_s2d_adain(const float* content, int64_t HWc, const float* style, int64_
 int tgtc_s2d_linear(const float* x, int64_t M, int K, const float* W, const float* b, int N, int relu, int precision,
                     float* y, void* stream);
 
+/* Backward of that layer for the training side (reference train_tgtcs.py:218-309 backpropagates through the NeRF MLPs):
+ *   dx[M,K] = dy[M,N] . W[N,K]        (NULL to skip)
+ *   dW[N,K] = dy^T . x,  db[N] = column sums of dy   (NULL to skip either)
+ * as GEMMs on the same kernel: dy and x are transposed into the workspace, the sample dimension is split over GEMM batches
+ * and the partial products summed.  dy is the gradient w.r.t. the layer's pre-activation output (apply
+ * tgtc_s2d_activation first when the forward fused a ReLU). */
+size_t tgtc_s2d_linear_backward_workspace_bytes(int64_t M, int K, int N);
+int tgtc_s2d_linear_backward(const float* x, const float* dy, const float* W, int64_t M, int K, int N, int precision,
+                             void* workspace, size_t workspace_bytes, float* dx, float* dW, float* db, void* stream);
+/* Elementwise helpers of the same path: mode 0 dx = dy * (y > 0) (ReLU backward), mode 1 dx = dy * y * (1 - y) (sigmoid
+ * backward), mode 2 dx = sigmoid(dy) (forward; y unused). */
+int tgtc_s2d_activation(const float* dy, const float* y, int64_t n, int mode, float* dx, void* stream);
+
 /* trans_test.py:172-173: bilinear resize, align_corners=True.  in [C,h,w] -> out [C,H,W]. */
 int tgtc_s2d_resize_bilinear(const float* in, int C, int h, int w, float* out, int H, int W, void* stream);
 /* trans_test.py:176: rows = hs_nchw.reshape(-1,512); feature = [rows.mean(0), rows.var(0)] (unbiased) -> [1024].

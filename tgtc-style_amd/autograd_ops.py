@@ -1,0 +1,81 @@
+"""Differentiable dense layers on the HIP GEMM kernel, for the training side of the reference (SURVEY section 8f rank 4:
+`Origin_train` / `Style_train`, train_tgtcs.py:218-571, backpropagate through the NeRF MLPs).
+
+The render path never needs these: it runs the fused kernels.  When a module's parameters require gradients its
+forward switches to this layer-by-layer form -- every product still a HIP kernel (`tgtc_s2d_linear`,
+`tgtc_s2d_linear_backward`: dx = dy.W, dW = dy^T.x with the sample dimension split over GEMM batches, db = column sums;
+`tgtc_s2d_activation` for ReLU / sigmoid), torch only records the graph and concatenates.  It is the plain form of the
+training arithmetic, not a fused one: a 196 k-sample batch costs about as much as the same layers through rocBLAS."""
+import torch
+
+from . import hip
+from . import style2d  # noqa: F401  (registers the ctypes signatures of the tgtc_s2d_* entries)
+
+
+def _ws(nbytes, device):
+    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, precision):
+        lib = hip.load()
+        x, w = x.float().contiguous(), weight.float().contiguous()
+        b = None if bias is None else bias.float().contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, device=x.device)
+        hip.check(lib.tgtc_s2d_linear(hip.ptr(x), M, K, hip.ptr(w), hip.ptr(b), N, int(relu), hip.PRECISIONS[precision], hip.ptr(y),
+                                      hip.stream()))
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.relu, ctx.precision, ctx.has_bias = relu, precision, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = hip.load()
+        x, w, y = ctx.saved_tensors
+        M, K = x.shape
+        N = w.shape[0]
+        dy = dy.float().contiguous()
+        if ctx.relu:
+            g = torch.empty_like(dy)
+            hip.check(lib.tgtc_s2d_activation(hip.ptr(dy), hip.ptr(y), dy.numel(), 0, hip.ptr(g), hip.stream()))
+            dy = g
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty_like(w) if need_w else None
+        db = torch.empty(N, device=x.device) if need_b else None
+        ws = _ws(lib.tgtc_s2d_linear_backward_workspace_bytes(M, K, N), x.device)
+        hip.check(lib.tgtc_s2d_linear_backward(hip.ptr(x), hip.ptr(dy), hip.ptr(w), M, K, N, hip.PRECISIONS[ctx.precision], hip.ptr(ws),
+                                               ws.numel() * 4, hip.ptr(dx), hip.ptr(dw), hip.ptr(db), hip.stream()))
+        return dx, dw, db, None, None
+
+
+class _Sigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = hip.load()
+        x = x.float().contiguous()
+        y = torch.empty_like(x)
+        hip.check(lib.tgtc_s2d_activation(hip.ptr(x), None, x.numel(), 2, hip.ptr(y), hip.stream()))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = hip.load()
+        (y,) = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(dy)
+        hip.check(lib.tgtc_s2d_activation(hip.ptr(dy), hip.ptr(y), dy.numel(), 1, hip.ptr(dx), hip.stream()))
+        return dx
+
+
+def linear(x, layer, relu=False, precision="fp16x3"):
+    """nn.Linear `layer` (+ ReLU) on x [M,K], differentiable w.r.t. x, weight and bias."""
+    return _Linear.apply(x, layer.weight, layer.bias, relu, precision)
+
+
+def sigmoid(x):
+    return _Sigmoid.apply(x)

@@ -122,6 +122,7 @@ struct GemmOut {
     float alpha;
     int relu;
     long long bias_batch_stride = 0; // floats between the bias vectors of consecutive batches (blockIdx.z)
+    const float* alpha_dev = nullptr; // optional second scale factor read from device memory (gradient rescaling)
 };
 
 // four fp32 values -> fp16 hi (+ lo) halves in LDS.  The lo halves come straight out of v_fma_mixlo/mixhi_f16
@@ -245,6 +246,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
     }
 
     // epilogue: lane holds rows m = .. + 4g + r, column n = .. + (lane & 15)
+    const float alpha = out.alpha_dev ? out.alpha * *out.alpha_dev : out.alpha;
 #pragma unroll
     for (int i = 0; i < WT; ++i)
 #pragma unroll
@@ -257,7 +259,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
                 const int m = m0 + 16 * WT * wm + 16 * i + 4 * g + r;
                 if (m >= M) continue;
                 const long long o = (long long)m * out.sm + (long long)n * out.sn;
-                float v = out.alpha * acc[i][j][r] + b;
+                float v = alpha * acc[i][j][r] + b;
                 if (out.res) v += out.res[o];
                 if (out.relu) v = fmaxf(v, 0.0f);
                 out.C[o] = v;
@@ -575,6 +577,78 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict_
     __syncthreads();
     for (int j = ty; j < 32; j += 8)
         if (bx + j < cols && by + tx < rows) out[(long long)(bx + j) * rows + by + tx] = tile[tx][j];
+}
+
+// ---- training-side dense layers (tgtc_s2d_linear_backward): helpers
+// [rows, cols] -> [cols, ld_out] (ld_out >= rows; the pad columns are cleared by the caller)
+__global__ void __launch_bounds__(256) transpose_ld_kernel(const float* __restrict__ in, long long rows, int cols,
+                                                           float* __restrict__ out, long long ld_out,
+                                                           const float* __restrict__ scale = nullptr) {
+    __shared__ float tile[32][33];
+    const long long by = (long long)blockIdx.y * 32;
+    const int bx = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (by + j < rows && bx + tx < cols) tile[j][tx] = in[(by + j) * cols + bx + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (bx + j < cols && by + tx < rows) out[(long long)(bx + j) * ld_out + by + tx] = tile[tx][j] * (scale ? *scale : 1.0f);
+}
+// Gradients arrive many orders of magnitude below 1 (a mean over the batch sits in front of them), below the range in which
+// an fp16 hi/lo split is exact.  They are rescaled by a power of two -- largest magnitude to ~2^10 -- on their way into the
+// GEMM operands and the products scaled back; the factor never leaves the device.
+//   sc[0] = bits of max |g| (atomicMax on the non-negative float's bits), then sc[1] = s, sc[2] = 1/s
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ g, long long n, unsigned* __restrict__ sc) {
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        m = max(m, __float_as_uint(fabsf(g[i])));
+#pragma unroll
+    for (int off = 32; off; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(sc, m);
+}
+__global__ void grad_scale_kernel(float* __restrict__ sc) {
+    const unsigned bits = reinterpret_cast<unsigned*>(sc)[0];
+    const int e = (int)((bits >> 23) & 0xff) - 127;            // max |g| in [2^e, 2^(e+1))
+    const bool ok = bits != 0 && ((bits >> 23) & 0xff) != 0xff;  // zero / inf / nan: leave the values alone
+    const int k = ok ? max(-100, min(100, 10 - e)) : 0;
+    sc[1] = ldexpf(1.0f, k), sc[2] = ldexpf(1.0f, -k);
+}
+__global__ void __launch_bounds__(256) scale_copy_kernel(const float* __restrict__ in, long long n, const float* __restrict__ sc,
+                                                         float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i] * sc[1];
+}
+// out[i] = sum_s part[s][i]
+__global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restrict__ part, int nsplit, long long n,
+                                                           float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int z = 0; z < nsplit; ++z) s += part[(long long)z * n + i];
+    out[i] = s;
+}
+// out[row] = sum of a row of length n (ld elements apart); one workgroup per row
+__global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ in, long long n, long long ld, float* __restrict__ out,
+                                                     const float* __restrict__ scale = nullptr) {
+    __shared__ float red[4];
+    const float* row = in + (long long)blockIdx.x * ld;
+    float s = 0.0f;
+    for (long long i = threadIdx.x; i < n; i += 256) s += row[i];
+#pragma unroll
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * (scale ? *scale : 1.0f);
+}
+// mode 0: dx = dy * (y > 0) (ReLU);  mode 1: dx = dy * y * (1 - y) (sigmoid);  mode 2: y = sigmoid(dy) (forward, `y` unused)
+__global__ void __launch_bounds__(256) act_kernel(const float* __restrict__ dy, const float* __restrict__ y, long long n,
+                                                  int mode, float* __restrict__ dx) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float g = dy[i];
+    if (mode == 0) dx[i] = y[i] > 0.0f ? g : 0.0f;
+    else if (mode == 1) dx[i] = g * y[i] * (1.0f - y[i]);
+    else dx[i] = 1.0f / (1.0f + expf(-g));
 }
 
 // per-channel mean and sqrt(unbiased var + eps) over HW; one workgroup per channel (function.py:4-12)
@@ -1173,6 +1247,98 @@ extern "C" int tgtc_s2d_linear(const float* x, int64_t M, int K, const float* W,
     tgtc_style2d h;
     h.precision = precision;
     return linear(&h, x, K, (int)M, K, W, b, N, y, N, nullptr, relu, as_stream(stream));
+}
+
+// split of the sample dimension for dW = dy^T . x: enough batches to fill the chip with 64x64 tiles, 32-aligned
+static void backward_split(int64_t M, int K, int N, int& nsplit, int64_t& mc) {
+    const long long tiles = (long long)((N + 63) / 64) * ((K + 63) / 64);
+    nsplit = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(64, (512 + tiles - 1) / tiles), (M + 1023) / 1024));
+    mc = ((M + nsplit - 1) / nsplit + 31) / 32 * 32;
+}
+
+extern "C" size_t tgtc_s2d_linear_backward_workspace_bytes(int64_t M, int K, int N) {
+    int nsplit;
+    int64_t mc;
+    backward_split(M, K, N, nsplit, mc);
+    const size_t mpad = (size_t)nsplit * mc;
+    return ((size_t)N * mpad + (size_t)K * mpad + (size_t)nsplit * N * K + (size_t)K * N + (size_t)M * N + 8 * 64) * sizeof(float);
+}
+
+extern "C" int tgtc_s2d_linear_backward(const float* x, const float* dy, const float* W, int64_t M, int K, int N,
+                                        int precision, void* workspace, size_t workspace_bytes, float* dx, float* dW,
+                                        float* db, void* stream) {
+    TGTC_REQUIRE(M >= 0 && M < 0x7fffffffLL && K > 0 && N > 0, "s2d_linear_backward: bad shape");
+    TGTC_REQUIRE(precision == TGTC_PREC_FP16 || precision == TGTC_PREC_FP16X3, "s2d_linear_backward: unknown precision %d", precision);
+    if (M == 0) return TGTC_OK;
+    TGTC_REQUIRE(dy && (!dx || W) && (!dW || x), "s2d_linear_backward: null pointer");
+    TGTC_REQUIRE(workspace && workspace_bytes >= tgtc_s2d_linear_backward_workspace_bytes(M, K, N), "s2d_linear_backward: workspace too small");
+    hipStream_t st = as_stream(stream);
+    tgtc_style2d h;
+    h.precision = precision;
+    int nsplit;
+    int64_t mc;
+    backward_split(M, K, N, nsplit, mc);
+    const long long mpad = (long long)nsplit * mc, mn = (long long)M * N;
+    Bump ws{static_cast<char*>(workspace), 0, workspace_bytes};
+    float* sc = ws.take(64);                       // [0] bits of max |dy|, [1] scale s (a power of two), [2] 1/s
+    float* dyT = ws.take((size_t)N * mpad);        // (s * dy)^T, zero padded to nsplit * mc samples
+    float* xT = ws.take((size_t)K * mpad);
+    float* part = ws.take((size_t)nsplit * N * K);
+    float* WT = ws.take((size_t)K * N);
+    float* dys = ws.take((size_t)mn);              // s * dy
+    if (!ws.ok) return fail(TGTC_ERR_ARG, "s2d_linear_backward: workspace too small");
+    TGTC_HIP_CHECK(hipMemsetAsync(sc, 0, 16, st));
+    absmax_kernel<<<(unsigned)std::min<long long>(1024, (mn + 255) / 256), 256, 0, st>>>(dy, mn, reinterpret_cast<unsigned*>(sc));
+    TGTC_LAUNCH_CHECK();
+    grad_scale_kernel<<<1, 1, 0, st>>>(sc);
+    TGTC_LAUNCH_CHECK();
+    if (dx) {   // dx[M,K] = dy[M,N] . W[N,K]: a linear layer on s*dy whose weight is W^T [K,N], scaled back by 1/s
+        scale_copy_kernel<<<(unsigned)((mn + 255) / 256), 256, 0, st>>>(dy, mn, sc, dys);
+        TGTC_LAUNCH_CHECK();
+        const dim3 g((K + 31) / 32, (N + 31) / 32);
+        transpose_ld_kernel<<<g, 256, 0, st>>>(W, N, K, WT, N);
+        TGTC_LAUNCH_CHECK();
+        DenseRows al{dys, N, 0, (int)M, N}, bl{WT, N, 0, K, N};
+        GemmOut out{dx, K, 1, 0, nullptr, nullptr, 1.0f, 0};
+        out.alpha_dev = sc + 2;
+        TGTC_TRY((launch_gemm<DenseRows, false>(&h, al, bl, out, (int)M, K, N, 1, st)));
+    }
+    if (dW || db) {
+        TGTC_HIP_CHECK(hipMemsetAsync(dyT, 0, (size_t)N * mpad * sizeof(float), st));
+        const dim3 g((N + 31) / 32, (unsigned)((M + 31) / 32));
+        transpose_ld_kernel<<<g, 256, 0, st>>>(dy, M, N, dyT, mpad, dW ? sc + 1 : nullptr);
+        TGTC_LAUNCH_CHECK();
+    }
+    if (dW) {   // dW[N,K] = sum over sample chunks of (s*dy)^T[N, chunk] . xT[K, chunk]^T, chunks as GEMM batches, times 1/s
+        TGTC_HIP_CHECK(hipMemsetAsync(xT, 0, (size_t)K * mpad * sizeof(float), st));
+        const dim3 g((K + 31) / 32, (unsigned)((M + 31) / 32));
+        transpose_ld_kernel<<<g, 256, 0, st>>>(x, M, K, xT, mpad);
+        TGTC_LAUNCH_CHECK();
+        DenseRows al{dyT, mpad, mc, N, (int)mc}, bl{xT, mpad, mc, K, (int)mc};
+        GemmOut out{nsplit > 1 ? part : dW, K, 1, (long long)N * K, nullptr, nullptr, 1.0f, 0};
+        out.alpha_dev = sc + 2;
+        TGTC_TRY((launch_gemm<DenseRows, false>(&h, al, bl, out, N, K, (int)mc, nsplit, st)));
+        if (nsplit > 1) {
+            const long long n = (long long)N * K;
+            sum_partials_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(part, nsplit, n, dW);
+            TGTC_LAUNCH_CHECK();
+        }
+    }
+    if (db) {   // column sums of dy = row sums of its transpose (scaled by s when dW shares the buffer)
+        rowsum_kernel<<<N, 256, 0, st>>>(dyT, M, mpad, db, dW ? sc + 2 : nullptr);
+        TGTC_LAUNCH_CHECK();
+    }
+    return TGTC_OK;
+}
+
+// mode 0: ReLU backward dx = dy * (y > 0); 1: sigmoid backward dx = dy * y * (1 - y); 2: sigmoid forward dx = sigmoid(dy)
+extern "C" int tgtc_s2d_activation(const float* dy, const float* y, int64_t n, int mode, float* dx, void* stream) {
+    TGTC_REQUIRE(n >= 0 && mode >= 0 && mode <= 2, "s2d_activation: bad argument");
+    if (n == 0) return TGTC_OK;
+    TGTC_REQUIRE(dy && dx && (mode == 2 || y), "s2d_activation: null pointer");
+    act_kernel<<<(unsigned)((n + 255) / 256), 256, 0, as_stream(stream)>>>(dy, y, n, mode, dx);
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
 }
 
 extern "C" int tgtc_s2d_mean_std(const float* feat, int C, int64_t HW, float eps, float* mean, float* std_,

@@ -6,7 +6,9 @@ reference: models.py:24-60 (Embedder), :63-117 (MLP_style), :120-147 (StyleMLP_b
 
 The modules own ordinary `nn.Parameter`s under the reference's names (so reference checkpoints
 `load_state_dict` directly); the packed fp16 weight stream the kernels read is (re)built lazily
-whenever the parameters change.  Forward only: the reference's render paths never backpropagate.
+whenever the parameters change.  The render paths never backpropagate and run the fused kernels; when gradients are
+enabled on a network marked `.trainable()` (the reference's training loops) StyleNerf / MLP_style switch to differentiable
+layer-by-layer HIP dense layers (autograd_ops.py).
 Select the arithmetic mode with `args.precision` = 'fp16x3' (default, fp32-equivalent) or 'fp16'.
 """
 from collections import OrderedDict
@@ -99,12 +101,38 @@ class MLP_style(_Packed):
     def _pack(self):
         return hip.nerf_create(self.state_dict(), self.precision, prefix="")
 
+    differentiable = False      # set True (StyleNerf.trainable()) to get gradients: the default is the fused forward-only path
+
+    def wants_grad(self):
+        return self.differentiable and torch.is_grad_enabled()
+
+    def forward_layers(self, pe, de):
+        """The same network layer by layer on differentiable HIP dense layers (autograd_ops.py): reference
+        models.py:95-111.  pe [M,63], de [M,27] float32 -> (rgb [M,3], base_remap [M,256], sigma [M])."""
+        from . import autograd_ops as ao
+        prec = self.precision if self.precision in ("fp16x3", "fp16") else "fp16x3"
+        base = ao.linear(pe, self.base_layers[0], True, prec)
+        for i in range(len(self.base_layers) - 1):
+            if i in self.skips:
+                base = torch.cat((pe, base), dim=-1)
+            base = ao.linear(base, self.base_layers[i + 1], True, prec)
+        sigma = ao.linear(base, self.sigma_layer, False, prec)
+        remap = ao.linear(base, self.base_remap_layer, True, prec)
+        fea = ao.linear(torch.cat((remap, de), dim=-1) if self.use_viewdir else remap, self.rgb_layers[0], True, prec)
+        rgb = ao.sigmoid(ao.linear(fea, self.rgb_layers[1], False, prec))
+        return rgb, remap, sigma.squeeze(-1)
+
     def forward(self, **kwargs):
         """pts [..,63], dirs [..,27] float32 (already encoded) -> dict rgb, base_remap, pts, sigma."""
         pts, dirs = kwargs['pts'], kwargs['dirs']
         hip.require_gpu(pts, dirs)
         lib = hip.load()
         lead = pts.shape[:-1]
+        if self.wants_grad():
+            rgb, remap, sigma = self.forward_layers(pts.reshape(-1, self.input_ch).to(torch.float32).contiguous(),
+                                                    dirs.reshape(-1, self.input_ch_viewdirs).to(torch.float32).contiguous())
+            return OrderedDict([('rgb', rgb.reshape(*lead, 3)), ('base_remap', remap.reshape(*lead, 256)),
+                                ('pts', pts), ('sigma', sigma.reshape(*lead))])
         p = pts.reshape(-1, self.input_ch).to(torch.float32).contiguous()
         d = dirs.reshape(-1, self.input_ch_viewdirs).to(torch.float32).contiguous()
         M = p.shape[0]
@@ -136,6 +164,12 @@ class StyleNerf(nn.Module):
         self.net.precision = _precision_of(args, mode)
         self.enable_style = enable_style
 
+    def trainable(self, on=True):
+        """Training side: forward through the differentiable layer-by-layer HIP dense layers whenever gradients are enabled
+        (the render paths stay on the fused kernels)."""
+        self.net.differentiable = bool(on)
+        return self
+
     def set_enable_style(self, enable_style=False):
         self.enable_style = enable_style
         self.net.enable_style = enable_style
@@ -149,6 +183,15 @@ class StyleNerf(nn.Module):
         hip.require_gpu(pts)
         lib = hip.load()
         lead = pts.shape[:-1]
+        if self.net.wants_grad():
+            # training side (train_tgtcs.py:218-309): encodings from the HIP encoder (no gradient: the samplers are detached
+            # in the reference too), then the differentiable layer-by-layer network
+            pe = self.embedder_coor(pts.reshape(-1, 3).detach())
+            de = self.embedder_dir(dirs.expand(*lead, 3).reshape(-1, 3).detach())
+            rgb, remap, sigma = self.net.forward_layers(pe, de)
+            return OrderedDict([('rgb', rgb.reshape(*lead, 3)), ('base_remap', remap.reshape(*lead, 256)),
+                                ('pts', pe.reshape(*lead, self.embedder_coor.out_dim)), ('sigma', sigma.reshape(*lead)),
+                                ('dirs', de.reshape(*lead, self.embedder_dir.out_dim))])
         p = pts.reshape(-1, 3).to(torch.float64).contiguous()
         d = dirs.expand(*lead, 3).reshape(-1, 3).to(torch.float64).contiguous()
         M = p.shape[0]
