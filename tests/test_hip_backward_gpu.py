@@ -61,7 +61,7 @@ def test_nerf_gradients_match_the_oracle():
     # the oracle's formulas with autograd, in float64 and -- as the yardstick of what float32 arithmetic does to these
     # gradients (ReLU gates of pre-activations within rounding of zero fall on either side) -- in float32
     def oracle_grads(dtype):
-        w = {k: v.to(dtype).requires_grad_() for k, v in T(sd).items()}
+        w = {k: v.clone().to(dtype).requires_grad_() for k, v in T(sd).items()}
         pts_o, ts_o = raymarch.sample_coarse(ro, rd, N, 0., 1., jitter=jit)
         pe = fields.posenc(pts_o, 10).to(dtype).reshape(R * N, -1)
         de = fields.posenc(rd[:, None, :].expand(R, N, 3), 4).to(dtype).reshape(R * N, -1)
@@ -123,3 +123,73 @@ def test_origin_train_step_reduces_the_loss():
         losses.append(r["loss"])
     print(losses)
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_style_mlp_gradients_match_the_oracle():
+    """The two style MLPs marked trainable: gradients w.r.t. every weight, the latent and the concat features against
+    float64 autograd on the oracle (Style_train's differentiable pieces, train_tgtcs.py:312-571)."""
+    from tgtc_style_amd import models
+    rng = np.random.default_rng(3)
+    M = 700
+    x = torch.from_numpy(rng.uniform(-1, 1, (M, 63)).astype(np.float32))
+    z = torch.from_numpy(rng.standard_normal((M, 32)).astype(np.float32))
+    remap = torch.from_numpy(np.maximum(rng.standard_normal((M, 256)), 0).astype(np.float32))
+    gt = torch.from_numpy(rng.uniform(0, 1, (M, 3)).astype(np.float32))
+    csd, ssd = synth.concat_state(2), synth.style_state(3)
+
+    cm, sm = models.StyleMLP_before_concat(Args), models.StyleMLP_Wild_multilayers(Args)
+    cm.load_state_dict(T(csd)), sm.load_state_dict(T(ssd))
+    cm, sm = cm.cuda().trainable(), sm.cuda().trainable()
+    cm.act_trace, sm.act_trace = [], []
+    zc = z.cuda().requires_grad_()
+    cf = cm(x=x.cuda(), latent=zc)["concat_features"]
+    rgb = sm(x=x.cuda(), concated=torch.cat([remap.cuda(), cf], -1), latent=zc)["rgb"]
+    ((rgb - gt.cuda()) ** 2).mean().backward()
+    c_gates = [(h > 0).cpu() for h in cm.act_trace]
+    s_gates = [(h > 0).cpu() for h in sm.act_trace]
+    assert len(c_gates) == 5 and len(s_gates) == 7
+
+    def oracle(dtype):
+        """The oracle's formulas (fields.concat_mlp / style_mlp) with each ReLU gate taken from the HIP forward: with 700
+        samples one pre-activation within rounding of zero falling on the other side would move a gradient by 1e-3."""
+        cw = {k: v.clone().to(dtype).requires_grad_() for k, v in T(csd).items()}
+        sw = {k: v.clone().to(dtype).requires_grad_() for k, v in T(ssd).items()}
+        zz = z.clone().to(dtype).requires_grad_()
+        xx = x.to(dtype)
+        lin = lambda w, i, h: torch.nn.functional.linear(h, w["layers.%d.weight" % i], w["layers.%d.bias" % i])
+        h = xx
+        for i in range(5):
+            h = torch.cat([h, zz], -1)
+            h = torch.cat([h, xx], -1) if i == 4 else h
+            h = lin(cw, i, h) * c_gates[i].to(dtype)
+        h = torch.cat([remap.to(dtype), h, xx], -1)
+        for i in range(7):
+            h = torch.cat([h, zz], -1)
+            h = torch.cat([h, xx], -1) if i == 4 else h
+            h = lin(sw, i, h) * s_gates[i].to(dtype)
+        rgb = torch.sigmoid(lin(sw, 7, torch.cat([h, zz], -1)))
+        ((rgb - gt.to(dtype)) ** 2).mean().backward()
+        g = {"c." + k: v.grad.double() for k, v in cw.items()}
+        g.update({"s." + k: v.grad.double() for k, v in sw.items()})
+        g["z"] = zz.grad.double()
+        return g, rgb.detach()
+    (g64, rgb64), (g32, _) = oracle(torch.float64), oracle(torch.float32)
+    assert float((rgb.detach().double().cpu() - rgb64).abs().max()) <= 2e-5
+    # the gated formulas are the oracle's: same outputs as fields.concat_mlp / fields.style_mlp
+    ref_cf = fields.concat_mlp(T(csd), x, z)["concat_features"]
+    ref_rgb = fields.style_mlp(T(ssd), x, torch.cat([remap, ref_cf], -1), z)["rgb"]
+    assert float((ref_rgb.double() - rgb64).abs().max()) <= 2e-5
+    got = {"c." + k: p.grad for k, p in cm.state_dict(keep_vars=True).items()}
+    got.update({"s." + k: p.grad for k, p in sm.state_dict(keep_vars=True).items()})
+    got["z"] = zc.grad
+    bad = []
+    for k, ref in g64.items():
+        scale = float(ref.abs().max()) + 1e-30
+        err = float((got[k].double().cpu() - ref).abs().max()) / scale
+        yard = float((g32[k] - ref).abs().max()) / scale
+        if err > max(2e-5, 3 * yard):
+            bad.append((k, err, yard))
+    assert not bad, bad
+    # not trainable: the packed kernels, no graph
+    out = sm.trainable(False)(x=x.cuda(), concated=torch.cat([remap.cuda(), cf.detach()], -1), latent=z.cuda())["rgb"]
+    assert not out.requires_grad and float((out - rgb.detach()).abs().max()) <= 2e-5

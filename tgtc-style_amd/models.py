@@ -231,6 +231,14 @@ class StyleMLP_before_concat(_Packed):
     def _pack(self):
         return hip.style_create(concat_state=self.state_dict(), precision=self.precision)
 
+    differentiable = False
+    act_trace = None            # tests: a list that receives every hidden activation of the differentiable forward
+
+    def trainable(self, on=True):
+        """Training side (Style_train, train_tgtcs.py:312-571): forward on the differentiable HIP dense layers."""
+        self.differentiable = bool(on)
+        return self
+
     def forward(self, **kwargs):
         x, latent = kwargs['x'], kwargs['latent']
         hip.require_gpu(x, latent)
@@ -238,6 +246,17 @@ class StyleMLP_before_concat(_Packed):
         lead = x.shape[:-1]
         xf = x.reshape(-1, 63).to(torch.float32).contiguous()
         lf = latent.expand(*lead, 32).reshape(-1, 32).to(torch.float32).contiguous()
+        if self.differentiable and torch.is_grad_enabled():       # models.py:137-147, layer by layer
+            from . import autograd_ops as ao
+            h = xf
+            for i, layer in enumerate(self.layers):
+                h = torch.cat([h, lf], -1)
+                if i in self.skips:
+                    h = torch.cat([h, xf], -1)
+                h = ao.linear(h, layer, True, self.precision)
+                if self.act_trace is not None:
+                    self.act_trace.append(h.detach())
+            return {'concat_features': h.reshape(*lead, 256)}
         out = torch.empty(xf.shape[0], 256, device=xf.device, dtype=torch.float32)
         hip.check(lib.tgtc_concat_mlp_forward(self._packed().handle, hip.ptr(xf), hip.ptr(lf), xf.shape[0],
                                               hip.ptr(out), hip.stream()))
@@ -266,6 +285,14 @@ class StyleMLP_Wild_multilayers(_Packed):
     def _pack(self):
         return hip.style_create(style_state=self.state_dict(), precision=self.precision)
 
+    differentiable = False
+    act_trace = None            # tests: a list that receives every hidden activation of the differentiable forward
+
+    def trainable(self, on=True):
+        """Training side (Style_train, train_tgtcs.py:312-571): forward on the differentiable HIP dense layers."""
+        self.differentiable = bool(on)
+        return self
+
     def forward(self, **kwargs):
         x, conc, latent = kwargs['x'], kwargs['concated'], kwargs['latent']
         hip.require_gpu(x, conc, latent)
@@ -274,6 +301,18 @@ class StyleMLP_Wild_multilayers(_Packed):
         xf = x.reshape(-1, 63).to(torch.float32).contiguous()
         cf = conc.reshape(-1, 512).to(torch.float32).contiguous()
         lf = latent.expand(*lead, 32).reshape(-1, 32).to(torch.float32).contiguous()
+        if self.differentiable and torch.is_grad_enabled():       # models.py:165-180, layer by layer
+            from . import autograd_ops as ao
+            h = torch.cat([cf, xf], -1)
+            for i, layer in enumerate(self.layers[:-1]):
+                h = torch.cat([h, lf], -1)
+                if i in self.skips:
+                    h = torch.cat([h, xf], -1)
+                h = ao.linear(h, layer, True, self.precision)
+                if self.act_trace is not None:
+                    self.act_trace.append(h.detach())
+            rgb = ao.sigmoid(ao.linear(torch.cat([h, lf], -1), self.layers[-1], False, self.precision))
+            return {'rgb': rgb.reshape(*lead, 3)}
         out = torch.empty(xf.shape[0], 3, device=xf.device, dtype=torch.float32)
         hip.check(lib.tgtc_style_mlp_forward(self._packed().handle, hip.ptr(xf), hip.ptr(cf), hip.ptr(lf),
                                              xf.shape[0], hip.ptr(out), hip.stream()))
