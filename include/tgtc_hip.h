@@ -143,6 +143,11 @@ int tgtc_render_rays_plain_chain(const tgtc_net* coarse, const tgtc_net* fine, c
  * style_ids / frame_ids int64 [R] device.  tile7: the llff `repeat((7,1))` wrap (models.py:496). */
 int tgtc_latents_forward(const float* latents, const float* mu, int S, int F, int D, const int64_t* style_ids,
                          const int64_t* frame_ids, int64_t R, float sigma_scale, int tile7, float* out, void* stream);
+/* Its gradient for the training side (Style_train optimises the table, train_tgtcs.py:312-571): grad_out [R,D] ->
+ * d_latents [S,F,D] += sigma_scale * g at the gathered rows, d_mu [S,D] += (1 - sigma_scale) * g; both buffers zeroed by the
+ * caller, either may be NULL. */
+int tgtc_latents_backward(const float* grad_out, int S, int F, int D, const int64_t* style_ids, const int64_t* frame_ids,
+                          int64_t R, float sigma_scale, int tile7, float* d_latents, float* d_mu, void* stream);
 
 /* ------------------------------------------------------------------ a13 (image epilogue)
  * rendering.py:66-71 (cal_geometry), :202-206 (render_style), :358-361 (render_train_style): what the drivers do to

@@ -193,3 +193,26 @@ def test_style_mlp_gradients_match_the_oracle():
     # not trainable: the packed kernels, no graph
     out = sm.trainable(False)(x=x.cuda(), concated=torch.cat([remap.cuda(), cf.detach()], -1), latent=z.cuda())["rgb"]
     assert not out.requires_grad and float((out - rgb.detach()).abs().max()) <= 2e-5
+
+
+def test_latent_table_gradients():
+    """StyleLatents_variational marked trainable: d/d latents and d/d mu of the gathered rows (models.py:490-506) against
+    autograd on the oracle's formula, with repeated rows and the x7 wrap."""
+    from tgtc_style_amd import models
+    sd = synth.latents_state(4, style_num=2, frame_num=20)
+    sid = torch.tensor([0, 0, 1, 1, 0, 1, 0, 1, 0, 0], dtype=torch.long)
+    fid = torch.tensor([0, 19, 3, 19, 25, 40, 119, 119, 0, 19], dtype=torch.long)
+    g = torch.from_numpy(np.random.default_rng(5).standard_normal((10, 32)).astype(np.float32))
+    for scale in (0.0, 0.35, 1.0):
+        w = {k: v.clone().double().requires_grad_() for k, v in T(sd).items()}
+        ref = fields.latents_forward(w, sid, fid, sigma_scale=scale, llff=True)
+        (ref * g.double()).sum().backward()
+        lat = models.StyleLatents_variational(style_num=2, frame_num=20, latent_dim=32)
+        lat.load_state_dict(T(sd))
+        lat = lat.cuda().trainable()
+        lat.sigma_scale = scale
+        out = lat(style_ids=sid.cuda(), frame_ids=fid.cuda(), type="llff")
+        (out * g.cuda()).sum().backward()
+        assert float((out.detach().cpu().double() - ref.detach()).abs().max()) <= 1e-6
+        assert float((lat.latents.grad.cpu().double() - w["latents"].grad).abs().max()) <= 1e-6
+        assert float((lat.style_latents_mu.grad.cpu().double() - w["style_latents_mu"].grad).abs().max()) <= 1e-6

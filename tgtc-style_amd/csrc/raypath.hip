@@ -399,6 +399,25 @@ __global__ void __launch_bounds__(256) latents_kernel(const float* __restrict__ 
     out[idx] = m + sigma_scale * (z - m);      // :504-505
 }
 
+// gradient of the same: d_latents[flat] += sigma_scale * g, d_mu[sid] += (1 - sigma_scale) * g (both pre-zeroed, atomics:
+// many rays share a row)
+__global__ void __launch_bounds__(256) latents_backward_kernel(const float* __restrict__ g, int S, int F, int D,
+                                                               const long long* __restrict__ style_ids,
+                                                               const long long* __restrict__ frame_ids, long long R,
+                                                               float sigma_scale, int tile7, float* __restrict__ d_latents,
+                                                               float* __restrict__ d_mu) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * D) return;
+    const long long r = idx / D;
+    const int c = (int)(idx % D);
+    const long long sid = style_ids[r];
+    long long flat = sid * F + frame_ids[r];
+    if (tile7) flat = flat % ((long long)S * F);
+    const float v = g[idx];
+    if (d_latents) atomicAdd(d_latents + flat * D + c, sigma_scale * v);
+    if (d_mu) atomicAdd(d_mu + sid * D + c, (1.0f - sigma_scale) * v);
+}
+
 }  // namespace tgtc
 
 using namespace tgtc;
@@ -576,6 +595,18 @@ extern "C" int tgtc_image_epilogue(const float* rgb, const float* t, int64_t fra
     if (frames == 0 || pixels == 0) return TGTC_OK;
     TGTC_REQUIRE((!rgb8 || rgb) && (!depth8 || t) && (rgb8 || depth8), "image_epilogue: null pointer");
     image_epilogue_kernel<<<(unsigned)frames, 1024, 0, as_stream(stream)>>>(rgb, t, pixels, eps, rgb8, depth8);
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
+}
+
+extern "C" int tgtc_latents_backward(const float* grad_out, int S, int F, int D, const int64_t* style_ids,
+                                     const int64_t* frame_ids, int64_t R, float sigma_scale, int tile7, float* d_latents,
+                                     float* d_mu, void* stream) {
+    TGTC_REQUIRE(S > 0 && F > 0 && D > 0 && R >= 0, "latents_backward: bad argument");
+    if (R == 0) return TGTC_OK;
+    TGTC_REQUIRE(grad_out && style_ids && frame_ids, "latents_backward: null pointer");
+    latents_backward_kernel<<<blocks_for(R * D, 256), 256, 0, as_stream(stream)>>>(
+        grad_out, S, F, D, (const long long*)style_ids, (const long long*)frame_ids, R, sigma_scale, tile7, d_latents, d_mu);
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;
 }

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "tgtc_image_epilogue": [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p],
     "tgtc_latents_forward": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_float, c_int,
                              c_void_p, c_void_p],
+    "tgtc_latents_backward": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_float, c_int, c_void_p, c_void_p, c_void_p],
 }
 _RESTYPES = {"tgtc_last_error": ctypes.c_char_p, "tgtc_render_workspace_bytes": c_size_t}
 _OPTIONAL = {

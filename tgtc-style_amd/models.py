@@ -365,6 +365,31 @@ class VAE(nn.Module):
         return mu, mu, log_var
 
 
+class _LatentGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, latents, mu, sid, fid, sigma_scale, tile7):
+        lib = hip.load()
+        S, F, D = latents.shape
+        out = torch.empty(sid.shape[0], D, device=latents.device, dtype=torch.float32)
+        hip.check(lib.tgtc_latents_forward(hip.ptr(latents.detach().float().contiguous()), hip.ptr(mu.detach().float().contiguous()), S, F, D,
+                                           hip.ptr(sid), hip.ptr(fid), sid.shape[0], sigma_scale, int(tile7), hip.ptr(out), hip.stream()))
+        ctx.save_for_backward(sid, fid)
+        ctx.shape, ctx.sigma_scale, ctx.tile7 = (S, F, D), sigma_scale, tile7
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = hip.load()
+        sid, fid = ctx.saved_tensors
+        S, F, D = ctx.shape
+        g = g.float().contiguous()
+        d_lat = torch.zeros(S, F, D, device=g.device) if ctx.needs_input_grad[0] else None
+        d_mu = torch.zeros(S, D, device=g.device) if ctx.needs_input_grad[1] else None
+        hip.check(lib.tgtc_latents_backward(hip.ptr(g), S, F, D, hip.ptr(sid), hip.ptr(fid), sid.shape[0], ctx.sigma_scale,
+                                            int(ctx.tile7), hip.ptr(d_lat), hip.ptr(d_mu), hip.stream()))
+        return d_lat, d_mu, None, None, None, None
+
+
 class StyleLatents_variational(nn.Module):
     """reference models.py:475-506, :535-539."""
 
@@ -398,9 +423,18 @@ class StyleLatents_variational(nn.Module):
         limit = 7 * rows if tile7 else rows
         if flat.numel() and (int(flat.max()) >= limit or int(flat.min()) < 0):
             raise IndexError("latent index out of range (%d rows%s)" % (rows, ", tiled x7" if tile7 else ""))
+        if torch.is_grad_enabled() and (self.latents.requires_grad or self.style_latents_mu.requires_grad) and self.differentiable:
+            return _LatentGather.apply(self.latents, self.style_latents_mu, sid, fid, float(self.sigma_scale), bool(tile7))
         out = torch.empty(sid.shape[0], self.latent_dim, device=dev, dtype=torch.float32)
         hip.check(lib.tgtc_latents_forward(hip.ptr(self.latents.detach().contiguous()),
                                            hip.ptr(self.style_latents_mu.detach().contiguous()), self.style_num,
                                            self.frame_num, self.latent_dim, hip.ptr(sid), hip.ptr(fid), sid.shape[0],
                                            float(self.sigma_scale), int(tile7), hip.ptr(out), hip.stream()))
         return out
+
+    differentiable = False
+
+    def trainable(self, on=True):
+        """Training side: the gather becomes differentiable w.r.t. the latent table and mu (tgtc_latents_backward)."""
+        self.differentiable = bool(on)
+        return self
