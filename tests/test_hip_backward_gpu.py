@@ -216,3 +216,38 @@ def test_latent_table_gradients():
         assert float((out.detach().cpu().double() - ref.detach()).abs().max()) <= 1e-6
         assert float((lat.latents.grad.cpu().double() - w["latents"].grad).abs().max()) <= 1e-6
         assert float((lat.style_latents_mu.grad.cpu().double() - w["style_latents_mu"].grad).abs().max()) <= 1e-6
+
+
+def test_style_train_step_reduces_the_loss():
+    """The rendering / pixel / -log p part of a Style_train iteration: the style MLPs and the latent table learn (their
+    parameters move, the loss falls) while the NeRF networks stay frozen on their fused kernels."""
+    from tgtc_style_amd import models, training
+    rng = np.random.default_rng(2)
+    R = 200
+    ro = torch.from_numpy(rng.uniform(-0.3, 0.3, (R, 3))).cuda()
+    rd = torch.from_numpy(rng.uniform(-1, 1, (R, 3)) * [0.4, 0.4, 0.1] + [0, 0, -1.0]).cuda()
+    gt = torch.from_numpy(rng.uniform(0.2, 0.8, (R, 3)).astype(np.float32)).cuda()
+    sid = torch.zeros(R, dtype=torch.long).cuda()
+    fid = torch.from_numpy(rng.integers(0, 20, R)).cuda()
+    model, model_fine = models.StyleNerf(Args, mode="coarse"), models.StyleNerf(Args, mode="fine")
+    model.load_state_dict(T(synth.nerf_state(0))), model_fine.load_state_dict(T(synth.nerf_state(1)))
+    model, model_fine = model.cuda(), model_fine.cuda()
+    model.set_enable_style(True), model_fine.set_enable_style(True)
+    cm, sm = models.StyleMLP_before_concat(Args), models.StyleMLP_Wild_multilayers(Args)
+    cm.load_state_dict(T(synth.concat_state(2))), sm.load_state_dict(T(synth.style_state(3)))
+    lat = models.StyleLatents_variational(style_num=1, frame_num=20, latent_dim=32)
+    lat.load_state_dict(T(synth.latents_state(4, style_num=1, frame_num=20)))
+    cm, sm, lat = cm.cuda().trainable(), sm.cuda().trainable(), lat.cuda().trainable()
+    lat.sigma_scale = 1.0
+    before = [p.detach().clone() for p in (cm.layers[0].weight, sm.layers[7].weight, lat.latents)]
+    nerf_before = model.net.base_layers[0].weight.detach().clone()
+    opt = torch.optim.Adam(list(cm.parameters()) + list(sm.parameters()) + [lat.latents], lr=1e-3)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    losses = [training.style_train_step(model, model_fine, cm, sm, lat, opt, ro, rd, gt, sid, fid, 64, 64, 0., 1., sigma_noise_std=0.1,
+                                        logp_loss_lambda=1e-3, jitter=torch.rand(R, 64, device="cuda", generator=gen))["loss"]
+              for _ in range(6)]
+    print(losses)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    after = (cm.layers[0].weight, sm.layers[7].weight, lat.latents)
+    assert all(float((a.detach() - b).abs().max()) > 0 for a, b in zip(after, before))
+    assert torch.equal(model.net.base_layers[0].weight.detach(), nerf_before) and model.net.base_layers[0].weight.grad is None

@@ -432,6 +432,15 @@ class StyleLatents_variational(nn.Module):
                                            float(self.sigma_scale), int(tile7), hip.ptr(out), hip.stream()))
         return out
 
+    def minus_logp(self, **kwargs):
+        """models.py:526-533: sum((z - mu)^2 / (exp(0.5 logvar) + 1e-3)) over the latent, mean over the rays (mu and logvar
+        detached).  Loss-side arithmetic on [R,32] tensors, as in the reference."""
+        style_ids, frame_ids = kwargs['style_ids'], kwargs['frame_ids']
+        z = self(style_ids=style_ids, frame_ids=frame_ids, type=kwargs['data_type'])
+        sid = style_ids.to(z.device).long()
+        mu, logvar = self.style_latents_mu.detach()[sid], self.style_latents_logvar.detach()[sid]
+        return torch.sum((z - mu) ** 2 / (torch.exp(0.5 * logvar) + 1e-3), -1).mean()
+
     differentiable = False
 
     def trainable(self, on=True):

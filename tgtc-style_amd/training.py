@@ -39,3 +39,41 @@ def origin_train_step(model, model_fine, optimizer, rays_o, rays_d, rgb_gt, N_sa
     optimizer.step()
     out.update(loss=float(loss.detach()), loss_rgb=float(loss_rgb.detach()))
     return out
+
+
+def style_train_step(model, model_fine, concat_model, style_model, latents, optimizer, rays_o, rays_d, rgb_gt, style_ids,
+                     frame_ids, N_samples, N_samples_fine, near, far, sigma_noise_std=1.0, rgb_loss_lambda=1.0,
+                     logp_loss_lambda=0.0, data_type='llff', jitter=None):
+    """The rendering, pixel and -log p terms of one `Style_train` iteration (train_tgtcs.py:404-482): the NeRF networks are
+    frozen feature extractors here (their fused forward, no graph), the concat / style MLPs and the latent table -- marked
+    `.trainable()` -- receive gradients through the HIP dense layers, the latent gather and compositing.  The VGG content /
+    style losses and the coherence term of the reference's later stages (:394-401, :456, :484-560) are not part of it."""
+    R = rays_o.shape[0]
+    z = latents(style_ids=style_ids, frame_ids=frame_ids, type=data_type)
+    zbar = torch.mean(z, dim=1, keepdim=True)
+    L = z.shape[-1]
+
+    def one_pass(nerf, pts, n):
+        with torch.no_grad():
+            ret = nerf(pts=pts, dirs=rays_d.unsqueeze(1).expand([R, n, 3]))
+        cf = concat_model(x=ret['pts'], latent=z.unsqueeze(1).expand([R, n, L]))['concat_features']
+        both = torch.cat((ret['base_remap'], cf), dim=-1)
+        rgb = style_model(x=ret['pts'], concated=both, latent=zbar.unsqueeze(2).expand([R, n, L]))['rgb']
+        return rgb, ret['sigma']
+
+    pts, ts = utils.sampling_pts_uniform(rays_o=rays_o, rays_d=rays_d, N_samples=N_samples, near=near, far=far, perturb=True,
+                                         jitter=jitter)
+    rgb, sigma = one_pass(model, pts, N_samples)
+    rgb_exp, _, weights = utils.alpha_composition(rgb, sigma, ts, sigma_noise_std)
+    loss_rgb = rgb_loss_lambda * img2mse(rgb_exp, rgb_gt)
+    loss_logp = logp_loss_lambda * latents.minus_logp(style_ids=style_ids, frame_ids=frame_ids, data_type=data_type)
+    if N_samples_fine > 0:
+        pts_f, ts_f = utils.sampling_pts_fine_torch(rays_o, rays_d, ts, weights.detach(), N_samples_fine)
+        rgb, sigma = one_pass(model_fine, pts_f, N_samples + N_samples_fine)
+        rgb_exp_fine, _, _ = utils.alpha_composition(rgb, sigma, ts_f, sigma_noise_std)
+        loss_rgb = loss_rgb + rgb_loss_lambda * img2mse(rgb_exp_fine, rgb_gt)
+    loss = loss_rgb + loss_logp
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return {'loss': float(loss.detach()), 'loss_rgb': float(loss_rgb.detach()), 'loss_logp': float(loss_logp.detach())}
