@@ -31,6 +31,10 @@ struct DenseRows {  // A(m,k) = p[m*ld + k]
     const float* p;
     long long ld, batch_stride;
     int rows, K;
+    // B operands that are network weights: the same matrix already split into fp16 hi / lo at handle creation (same
+    // indexing as p), or null
+    const half_t* h16 = nullptr;
+    const half_t* l16 = nullptr;
     struct Ctx { const float* row; };
     __device__ Ctx prep(int m) const { return Ctx{m < rows ? p + (long long)m * ld : nullptr}; }
     __device__ void load4(const Ctx& c, int k0, int kq, float (&v)[4]) const {
@@ -149,9 +153,12 @@ __device__ __forceinline__ void put4(half_t* hi, half_t* lo, const float (&v)[4]
 // k-major matrix B[k][n] = p[k*ld + n] (the V operand of attention).
 // WT = 16x16 accumulator tiles per wave and dimension: 4 -> 128x128 workgroup tiles, 2 -> 64x64, 1 -> 32x32 (launch_gemm
 // picks; a [2500,512] projection is only 20x4 tiles of 128x128 on 256 CUs).
-template <class AL, bool SPLIT, bool B_KMAJOR, int WT>
+// B_PRE: the B rows come pre-split (DenseRows::h16 / l16, K a multiple of 4): two 8-byte loads per quad go straight to LDS,
+// no conversion in the loop.
+template <class AL, bool SPLIT, bool B_KMAJOR, int WT, bool B_PRE = false>
 __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut out, int M, int N, int K) {
     constexpr int NP = SPLIT ? 2 : 1;
+    static_assert(!(B_PRE && B_KMAJOR), "pre-split weights are row operands");
     constexpr int BM = 32 * WT, BN = 32 * WT;
     static_assert(!B_KMAJOR || WT == 4, "the k-major B loader is written for 128-wide tiles");
     __shared__ __attribute__((aligned(16))) half_t sA[NP][BM][LDK];
@@ -162,6 +169,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     al.p += (long long)blockIdx.z * al.batch_stride;
     bl.p += (long long)blockIdx.z * bl.batch_stride;
+    if constexpr (B_PRE) bl.h16 += (long long)blockIdx.z * bl.batch_stride, bl.l16 += (long long)blockIdx.z * bl.batch_stride;
     out.C += (long long)blockIdx.z * out.batch_stride;
     if (out.res) out.res += (long long)blockIdx.z * out.batch_stride;
     if (out.bias) out.bias += (long long)blockIdx.z * out.bias_batch_stride;
@@ -178,12 +186,19 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
     // k-major B: thread covers k = (tid>>5) + 8i, n-quad (tid&31)*4
     const int bk = tid >> 5, bnq = (tid & 31) * 4;
 
-    float ra[WT][4], rb[WT][4];
+    float ra[WT][4], rb[B_PRE ? 1 : WT][4];
+    uint2 rbh[B_PRE ? WT : 1], rbl[B_PRE ? WT : 1];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
             al.load4(actx[i], k0, skq, ra[i]);
-            if constexpr (!B_KMAJOR) {
+            if constexpr (B_PRE) {
+                const int row = n0 + srow + 32 * i, k = k0 + skq;
+                const bool ok = row < bl.rows && k < bl.K;     // K % 4 == 0: a quad is inside or outside as a whole
+                const long long o = (long long)row * bl.ld + k;
+                rbh[i] = ok ? *reinterpret_cast<const uint2*>(bl.h16 + o) : uint2{0u, 0u};
+                if constexpr (SPLIT) rbl[i] = ok ? *reinterpret_cast<const uint2*>(bl.l16 + o) : uint2{0u, 0u};
+            } else if constexpr (!B_KMAJOR) {
                 bl.load4(bctx[i], k0, skq, rb[i]);
             } else {
                 const int k = k0 + bk + 8 * i;
@@ -197,7 +212,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
             put4<SPLIT>(&sA[0][srow + 32 * i][skq], &sA[NP - 1][srow + 32 * i][skq], ra[i]);
-            if constexpr (!B_KMAJOR) {
+            if constexpr (B_PRE) {
+                *reinterpret_cast<uint2*>(&sB[0][srow + 32 * i][skq]) = rbh[i];
+                if constexpr (SPLIT) *reinterpret_cast<uint2*>(&sB[1][srow + 32 * i][skq]) = rbl[i];
+            } else if constexpr (!B_KMAJOR) {
                 put4<SPLIT>(&sB[0][srow + 32 * i][skq], &sB[NP - 1][srow + 32 * i][skq], rb[i]);
             } else {
 #pragma unroll
@@ -761,6 +779,11 @@ struct tgtc_style2d {
     int precision;
     std::vector<float*> allocs;
     std::map<std::string, const float*> tr, emb, dec, vgg;  // device pointers by reference key name
+    // every uploaded parameter group also as fp16 hi / lo halves (GEMM B operands skip the conversion): for a float pointer
+    // p inside [base, base + n) the halves are hi16 + (p - base), lo16 + (p - base)
+    struct Pre { const float* base; size_t n; const tgtc::half_t* hi16; const tgtc::half_t* lo16; };
+    std::vector<Pre> pre;
+    std::vector<void*> allocs16;
 };
 
 namespace tgtc {
@@ -779,15 +802,34 @@ static int launch_gemm(const tgtc_style2d* h, AL al, DenseRows bl, GemmOut out, 
         if (split) gemm_kernel<AL, true, true, 4><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
         else gemm_kernel<AL, false, true, 4><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
     } else {
+        // weights of this handle: take their pre-split halves (8-byte aligned quads need K, ld and the offset multiples of 4)
+        bool pre = false;
+        if constexpr (std::is_same<AL, DenseRows>::value || std::is_same<AL, ConvNHWC>::value) {
+            for (const auto& r : h->pre)
+                if (bl.p >= r.base && bl.p < r.base + r.n && K % 4 == 0 && bl.ld % 4 == 0 && bl.batch_stride % 4 == 0 && (bl.p - r.base) % 4 == 0) {
+                    bl.h16 = r.hi16 + (bl.p - r.base), bl.l16 = r.lo16 + (bl.p - r.base), pre = true;
+                    break;
+                }
+        }
         const long long mid = (long long)((M + 63) / 64) * ((N + 63) / 64) * batch;
-        if (mid < 400) {
-            dim3 grid((M + 31) / 32, (N + 31) / 32, batch);
-            if (split) gemm_kernel<AL, true, false, 1><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
-            else gemm_kernel<AL, false, false, 1><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+        auto go = [&](auto wt_, auto pre_) {
+            constexpr int WT = decltype(wt_)::value;
+            constexpr bool PRE = decltype(pre_)::value;
+            dim3 grid((M + 32 * WT - 1) / (32 * WT), (N + 32 * WT - 1) / (32 * WT), batch);
+            if (split) gemm_kernel<AL, true, false, WT, PRE><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+            else gemm_kernel<AL, false, false, WT, PRE><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+        };
+        if constexpr (std::is_same<AL, DenseRows>::value || std::is_same<AL, ConvNHWC>::value) {
+            if (pre) {
+                if (mid < 400) go(ic<1>{}, std::true_type{});
+                else go(ic<2>{}, std::true_type{});
+            } else {
+                if (mid < 400) go(ic<1>{}, std::false_type{});
+                else go(ic<2>{}, std::false_type{});
+            }
         } else {
-            dim3 grid((M + 63) / 64, (N + 63) / 64, batch);
-            if (split) gemm_kernel<AL, true, false, 2><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
-            else gemm_kernel<AL, false, false, 2><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
+            if (mid < 400) go(ic<1>{}, std::false_type{});
+            else go(ic<2>{}, std::false_type{});
         }
     }
     TGTC_LAUNCH_CHECK();
@@ -1029,6 +1071,17 @@ static int upload_group(tgtc_style2d* h, const tgtc_named_tensor* t, int n, std:
     h->allocs.push_back(dev);
     TGTC_HIP_CHECK(hipMemcpy(dev, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
     for (int i = 0; i < n; ++i) dst[t[i].name] = dev + offs[i];
+    // fp16 hi / lo copies of the whole group (weights are what the GEMMs read as B operands)
+    std::vector<half_t> h16(2 * total);
+    for (size_t i = 0; i < total; ++i) {
+        const half_t hi = (half_t)host[i];
+        h16[i] = hi, h16[total + i] = (half_t)(host[i] - (float)hi);
+    }
+    half_t* dev16 = nullptr;
+    TGTC_HIP_CHECK(hipMalloc((void**)&dev16, 2 * total * sizeof(half_t)));
+    h->allocs16.push_back(dev16);
+    TGTC_HIP_CHECK(hipMemcpy(dev16, h16.data(), 2 * total * sizeof(half_t), hipMemcpyHostToDevice));
+    h->pre.push_back({dev, total, dev16, dev16 + total});
     return TGTC_OK;
 }
 
@@ -1055,6 +1108,7 @@ extern "C" int tgtc_s2d_create(const tgtc_named_tensor* transformer, int n_trans
 extern "C" int tgtc_s2d_destroy(tgtc_style2d* h) {
     if (!h) return TGTC_OK;
     for (float* p : h->allocs) (void)hipFree(p);
+    for (void* p : h->allocs16) (void)hipFree(p);
     delete h;
     return TGTC_OK;
 }
