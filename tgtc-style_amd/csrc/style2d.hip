@@ -1358,13 +1358,15 @@ extern "C" int tgtc_s2d_linear_backward(const float* x, const float* dy, const f
         TGTC_TRY((launch_gemm<DenseRows, false>(&h, al, bl, out, (int)M, K, N, 1, st)));
     }
     if (dW || db) {
-        TGTC_HIP_CHECK(hipMemsetAsync(dyT, 0, (size_t)N * mpad * sizeof(float), st));
+        if (mpad > M)   // only the pad columns: the transpose writes the rest
+            TGTC_HIP_CHECK(hipMemset2DAsync(dyT + M, (size_t)mpad * sizeof(float), 0, (size_t)(mpad - M) * sizeof(float), N, st));
         const dim3 g((N + 31) / 32, (unsigned)((M + 31) / 32));
         transpose_ld_kernel<<<g, 256, 0, st>>>(dy, M, N, dyT, mpad, dW ? sc + 1 : nullptr);
         TGTC_LAUNCH_CHECK();
     }
     if (dW) {   // dW[N,K] = sum over sample chunks of (s*dy)^T[N, chunk] . xT[K, chunk]^T, chunks as GEMM batches, times 1/s
-        TGTC_HIP_CHECK(hipMemsetAsync(xT, 0, (size_t)K * mpad * sizeof(float), st));
+        if (mpad > M)
+            TGTC_HIP_CHECK(hipMemset2DAsync(xT + M, (size_t)mpad * sizeof(float), 0, (size_t)(mpad - M) * sizeof(float), K, st));
         const dim3 g((K + 31) / 32, (unsigned)((M + 31) / 32));
         transpose_ld_kernel<<<g, 256, 0, st>>>(x, M, K, xT, mpad);
         TGTC_LAUNCH_CHECK();
