@@ -275,6 +275,9 @@ def run_headline(args, precision, rank, world, dist):
     pf = precision.split("+")[-1]
     kname = "fused_render_kernel" if fused else "per-sample kernel chain"
     traffic, provenance = pmc_traffic("fused_render_kernel:%s" % precision) if fused else (None, "chain: not profiled")
+    if traffic and rays_launch != n_rays:   # the PMC pass profiled whole-frame launches; a ray range streams in proportion
+        traffic *= rays_launch / n_rays
+        provenance += "; scaled by %d / %d rays of this launch" % (rays_launch, n_rays)
     algo_bytes = rays_launch * BYTES_PER_RAY
     return {
         "metric": "rays/sec (128c+64f samples) on fern 400x400",
