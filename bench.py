@@ -182,6 +182,32 @@ def bench_style2d(precision, steps, warmup):
                          "note": "all kernels of the pass together (HIP events around the frame)"}}
 
 
+def bench_train_step(steps, warmup, rays=1024):
+    """one iteration of the reference's Origin_train body (coarse + fine losses, sigma noise, Adam) on
+    the differentiable, unfused HIP dense layers.  ms per iteration."""
+    from tgtc_style_amd import models, synth, training
+    rng = np.random.default_rng(1)
+    ro = torch.from_numpy(rng.uniform(-0.3, 0.3, (rays, 3))).cuda()
+    rd = torch.from_numpy(rng.uniform(-1, 1, (rays, 3)) * [0.4, 0.4, 0.1] + [0, 0, -1.0]).cuda()
+    gt = torch.from_numpy(rng.uniform(0.2, 0.8, (rays, 3)).astype(np.float32)).cuda()
+    m, mf = models.StyleNerf(NetArgs, mode="coarse"), models.StyleNerf(NetArgs, mode="fine")
+    m.load_state_dict(t_state(synth.nerf_state(0))), mf.load_state_dict(t_state(synth.nerf_state(1)))
+    m, mf = m.cuda().trainable(), mf.cuda().trainable()
+    opt = torch.optim.Adam(list(m.parameters()) + list(mf.parameters()), lr=5e-4)
+    for i in range(warmup + steps):
+        if i == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        r = training.origin_train_step(m, mf, opt, ro, rd, gt, 64, 64, 0., 1., sigma_noise_std=0.1)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    samples = rays * (64 + 128)
+    assert np.isfinite(r["loss"])
+    return {"metric": "ms per Origin_train iteration (1024 rays, 64 coarse + 128 fine-pass network samples, forward + backward + Adam) "
+                      "on the unfused differentiable HIP dense layers", "value": ms, "unit": "ms", "higher_is_better": False,
+            "steps": steps, "dtype": "fp16x3", "network_samples_per_s": samples / (ms * 1e-3)}
+
+
 def make_renderer(precision, styled):
     from tgtc_style_amd import models, rendering, synth
     coarse, fine = build_nets(precision)
@@ -325,7 +351,7 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=8192, help="rays of the CPU baseline sample (0 disables)")
     ap.add_argument("--alt-precision", default="fp16x3,fp16",
                     help="further precisions (comma separated) reported under `alt_precisions` ('' disables)")
-    ap.add_argument("--configs", default="styled,style2d,trex_rays",
+    ap.add_argument("--configs", default="styled,style2d,trex_rays,train_step",
                     help="N = 1: further BASELINE configs measured after the headline and reported under `configs` ('' disables)")
     args = ap.parse_args()
 
@@ -367,6 +393,8 @@ def main():
             if "trex_rays" in wanted:   # BASELINE config 4's frame on one GPU (its 8 ray ranges are this frame's slices)
                 cfg["trex_rays"] = dict(bench_frame(args.precision, 378, 504, short, 1),
                                         metric="rays/sec (128c+64f) on a whole trex 504x378 frame (190512 rays), one GPU")
+            if "train_step" in wanted:  # SURVEY 8f rank 4 (training side), unfused
+                cfg["train_step"] = bench_train_step(6, 3)
             if cfg:
                 line["configs"] = cfg
             if args.cpu_rays > 0:
