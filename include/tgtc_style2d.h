@@ -97,11 +97,12 @@ int tgtc_s2d_linear(const float* x, int64_t M, int K, const float* W, const floa
  *   dx[M,K] = dy[M,N] . W[N,K]        (NULL to skip)
  *   dW[N,K] = dy^T . x,  db[N] = column sums of dy   (NULL to skip either)
  * as GEMMs on the same kernel: dy and x are transposed into the workspace, the sample dimension is split over GEMM batches
- * and the partial products summed.  dy is the gradient w.r.t. the layer's pre-activation output (apply
- * tgtc_s2d_activation first when the forward fused a ReLU). */
+ * and the partial products summed.  relu_y (NULL, or the forward's output [M,N] when it fused a ReLU) gates dy on the fly:
+ * elements with relu_y <= 0 carry no gradient. */
 size_t tgtc_s2d_linear_backward_workspace_bytes(int64_t M, int K, int N);
-int tgtc_s2d_linear_backward(const float* x, const float* dy, const float* W, int64_t M, int K, int N, int precision,
-                             void* workspace, size_t workspace_bytes, float* dx, float* dW, float* db, void* stream);
+int tgtc_s2d_linear_backward(const float* x, const float* dy, const float* relu_y, const float* W, int64_t M, int K, int N,
+                             int precision, void* workspace, size_t workspace_bytes, float* dx, float* dW, float* db,
+                             void* stream);
 /* Elementwise helpers of the same path: mode 0 dx = dy * (y > 0) (ReLU backward), mode 1 dx = dy * y * (1 - y) (sigmoid
  * backward), mode 2 dx = sigmoid(dy) (forward; y unused). */
 int tgtc_s2d_activation(const float* dy, const float* y, int64_t n, int mode, float* dx, void* stream);

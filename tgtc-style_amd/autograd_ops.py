@@ -37,17 +37,13 @@ class _Linear(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         M, K = x.shape
         N = w.shape[0]
-        dy = dy.float().contiguous()
-        if ctx.relu:
-            g = torch.empty_like(dy)
-            hip.check(lib.tgtc_s2d_activation(hip.ptr(dy), hip.ptr(y), dy.numel(), 0, hip.ptr(g), hip.stream()))
-            dy = g
+        dy = dy.float().contiguous()        # gated by the forward's ReLU inside the backward kernels (relu_y)
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dx = torch.empty_like(x) if need_x else None
         dw = torch.empty_like(w) if need_w else None
         db = torch.empty(N, device=x.device) if need_b else None
         ws = _ws(lib.tgtc_s2d_linear_backward_workspace_bytes(M, K, N), x.device)
-        hip.check(lib.tgtc_s2d_linear_backward(hip.ptr(x), hip.ptr(dy), hip.ptr(w), M, K, N, hip.PRECISIONS[ctx.precision], hip.ptr(ws),
+        hip.check(lib.tgtc_s2d_linear_backward(hip.ptr(x), hip.ptr(dy), hip.ptr(y) if ctx.relu else None, hip.ptr(w), M, K, N, hip.PRECISIONS[ctx.precision], hip.ptr(ws),
                                                ws.numel() * 4, hip.ptr(dx), hip.ptr(dw), hip.ptr(db), hip.stream()))
         return dx, dw, db, None, None
 

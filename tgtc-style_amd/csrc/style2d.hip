@@ -599,15 +599,21 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict_
 
 // ---- training-side dense layers (tgtc_s2d_linear_backward): helpers
 // [rows, cols] -> [cols, ld_out] (ld_out >= rows; the pad columns are cleared by the caller)
+// (`gate`, optional, same shape as `in`: elements whose gate is <= 0 read as zero -- the ReLU of the forward, applied to the
+// incoming gradient on the fly)
 __global__ void __launch_bounds__(256) transpose_ld_kernel(const float* __restrict__ in, long long rows, int cols,
                                                            float* __restrict__ out, long long ld_out,
-                                                           const float* __restrict__ scale = nullptr) {
+                                                           const float* __restrict__ scale = nullptr,
+                                                           const float* __restrict__ gate = nullptr) {
     __shared__ float tile[32][33];
     const long long by = (long long)blockIdx.y * 32;
     const int bx = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int j = ty; j < 32; j += 8)
-        if (by + j < rows && bx + tx < cols) tile[j][tx] = in[(by + j) * cols + bx + tx];
+        if (by + j < rows && bx + tx < cols) {
+            const long long o = (by + j) * cols + bx + tx;
+            tile[j][tx] = (gate && !(gate[o] > 0.0f)) ? 0.0f : in[o];
+        }
     __syncthreads();
     for (int j = ty; j < 32; j += 8)
         if (bx + j < cols && by + tx < rows) out[(long long)(bx + j) * ld_out + by + tx] = tile[tx][j] * (scale ? *scale : 1.0f);
@@ -616,10 +622,11 @@ __global__ void __launch_bounds__(256) transpose_ld_kernel(const float* __restri
 // an fp16 hi/lo split is exact.  They are rescaled by a power of two -- largest magnitude to ~2^10 -- on their way into the
 // GEMM operands and the products scaled back; the factor never leaves the device.
 //   sc[0] = bits of max |g| (atomicMax on the non-negative float's bits), then sc[1] = s, sc[2] = 1/s
-__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ g, long long n, unsigned* __restrict__ sc) {
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ g, long long n, unsigned* __restrict__ sc,
+                                                     const float* __restrict__ gate) {
     unsigned m = 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        m = max(m, __float_as_uint(fabsf(g[i])));
+        if (!gate || gate[i] > 0.0f) m = max(m, __float_as_uint(fabsf(g[i])));
 #pragma unroll
     for (int off = 32; off; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(sc, m);
@@ -632,9 +639,9 @@ __global__ void grad_scale_kernel(float* __restrict__ sc) {
     sc[1] = ldexpf(1.0f, k), sc[2] = ldexpf(1.0f, -k);
 }
 __global__ void __launch_bounds__(256) scale_copy_kernel(const float* __restrict__ in, long long n, const float* __restrict__ sc,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, const float* __restrict__ gate) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = in[i] * sc[1];
+    if (i < n) out[i] = (gate && !(gate[i] > 0.0f)) ? 0.0f : in[i] * sc[1];
 }
 // out[i] = sum_s part[s][i]
 __global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restrict__ part, int nsplit, long long n,
@@ -645,18 +652,19 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restri
     for (int z = 0; z < nsplit; ++z) s += part[(long long)z * n + i];
     out[i] = s;
 }
-// out[row] = sum of a row of length n (ld elements apart); one workgroup per row
-__global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ in, long long n, long long ld, float* __restrict__ out,
-                                                     const float* __restrict__ scale = nullptr) {
+// out[row] += scale * sum of in[row][chunk]: one workgroup per (row, chunk of `mc` elements), out pre-zeroed
+__global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ in, long long n, long long ld, long long mc,
+                                                     float* __restrict__ out, const float* __restrict__ scale = nullptr) {
     __shared__ float red[4];
+    const long long lo = (long long)blockIdx.y * mc, hi = min(n, lo + mc);
     const float* row = in + (long long)blockIdx.x * ld;
     float s = 0.0f;
-    for (long long i = threadIdx.x; i < n; i += 256) s += row[i];
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) s += row[i];
 #pragma unroll
     for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * (scale ? *scale : 1.0f);
+    if (threadIdx.x == 0) atomicAdd(out + blockIdx.x, (red[0] + red[1] + red[2] + red[3]) * (scale ? *scale : 1.0f));
 }
 // mode 0: dx = dy * (y > 0) (ReLU);  mode 1: dx = dy * y * (1 - y) (sigmoid);  mode 2: y = sigmoid(dy) (forward, `y` unused)
 __global__ void __launch_bounds__(256) act_kernel(const float* __restrict__ dy, const float* __restrict__ y, long long n,
@@ -1318,8 +1326,8 @@ extern "C" size_t tgtc_s2d_linear_backward_workspace_bytes(int64_t M, int K, int
     return ((size_t)N * mpad + (size_t)K * mpad + (size_t)nsplit * N * K + (size_t)K * N + (size_t)M * N + 8 * 64) * sizeof(float);
 }
 
-extern "C" int tgtc_s2d_linear_backward(const float* x, const float* dy, const float* W, int64_t M, int K, int N,
-                                        int precision, void* workspace, size_t workspace_bytes, float* dx, float* dW,
+extern "C" int tgtc_s2d_linear_backward(const float* x, const float* dy, const float* relu_y, const float* W, int64_t M, int K,
+                                        int N, int precision, void* workspace, size_t workspace_bytes, float* dx, float* dW,
                                         float* db, void* stream) {
     TGTC_REQUIRE(M >= 0 && M < 0x7fffffffLL && K > 0 && N > 0, "s2d_linear_backward: bad shape");
     TGTC_REQUIRE(precision == TGTC_PREC_FP16 || precision == TGTC_PREC_FP16X3, "s2d_linear_backward: unknown precision %d", precision);
@@ -1342,12 +1350,12 @@ extern "C" int tgtc_s2d_linear_backward(const float* x, const float* dy, const f
     float* dys = ws.take((size_t)mn);              // s * dy
     if (!ws.ok) return fail(TGTC_ERR_ARG, "s2d_linear_backward: workspace too small");
     TGTC_HIP_CHECK(hipMemsetAsync(sc, 0, 16, st));
-    absmax_kernel<<<(unsigned)std::min<long long>(1024, (mn + 255) / 256), 256, 0, st>>>(dy, mn, reinterpret_cast<unsigned*>(sc));
+    absmax_kernel<<<(unsigned)std::min<long long>(1024, (mn + 255) / 256), 256, 0, st>>>(dy, mn, reinterpret_cast<unsigned*>(sc), nullptr);   // ungated maximum >= gated one: as good a scale, half the bytes
     TGTC_LAUNCH_CHECK();
     grad_scale_kernel<<<1, 1, 0, st>>>(sc);
     TGTC_LAUNCH_CHECK();
     if (dx) {   // dx[M,K] = dy[M,N] . W[N,K]: a linear layer on s*dy whose weight is W^T [K,N], scaled back by 1/s
-        scale_copy_kernel<<<(unsigned)((mn + 255) / 256), 256, 0, st>>>(dy, mn, sc, dys);
+        scale_copy_kernel<<<(unsigned)((mn + 255) / 256), 256, 0, st>>>(dy, mn, sc, dys, relu_y);
         TGTC_LAUNCH_CHECK();
         const dim3 g((K + 31) / 32, (N + 31) / 32);
         transpose_ld_kernel<<<g, 256, 0, st>>>(W, N, K, WT, N);
@@ -1361,7 +1369,7 @@ extern "C" int tgtc_s2d_linear_backward(const float* x, const float* dy, const f
         if (mpad > M)   // only the pad columns: the transpose writes the rest
             TGTC_HIP_CHECK(hipMemset2DAsync(dyT + M, (size_t)mpad * sizeof(float), 0, (size_t)(mpad - M) * sizeof(float), N, st));
         const dim3 g((N + 31) / 32, (unsigned)((M + 31) / 32));
-        transpose_ld_kernel<<<g, 256, 0, st>>>(dy, M, N, dyT, mpad, dW ? sc + 1 : nullptr);
+        transpose_ld_kernel<<<g, 256, 0, st>>>(dy, M, N, dyT, mpad, dW ? sc + 1 : nullptr, relu_y);
         TGTC_LAUNCH_CHECK();
     }
     if (dW) {   // dW[N,K] = sum over sample chunks of (s*dy)^T[N, chunk] . xT[K, chunk]^T, chunks as GEMM batches, times 1/s
@@ -1381,7 +1389,8 @@ extern "C" int tgtc_s2d_linear_backward(const float* x, const float* dy, const f
         }
     }
     if (db) {   // column sums of dy = row sums of its transpose (scaled by s when dW shares the buffer)
-        rowsum_kernel<<<N, 256, 0, st>>>(dyT, M, mpad, db, dW ? sc + 2 : nullptr);
+        TGTC_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st));
+        rowsum_kernel<<<dim3(N, nsplit), 256, 0, st>>>(dyT, M, mpad, mc, db, dW ? sc + 2 : nullptr);
         TGTC_LAUNCH_CHECK();
     }
     return TGTC_OK;
