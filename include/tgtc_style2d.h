@@ -93,6 +93,12 @@ int tgtc_s2d_adain(const float* content, int64_t HWc, const float* style, int64_
 int tgtc_s2d_linear(const float* x, int64_t M, int K, const float* W, const float* b, int N, int relu, int precision,
                     float* y, void* stream);
 
+/* The same with the weight also handed in as fp16 hi / lo halves (made by tgtc_s2d_split, n = N*K; used when K % 4 == 0): the
+ * GEMM loads them without converting. */
+int tgtc_s2d_split(const float* w, int64_t n, void* hi, void* lo, void* stream);
+int tgtc_s2d_linear_pre(const float* x, int64_t M, int K, const float* W, const void* W_hi, const void* W_lo, const float* b,
+                        int N, int relu, int precision, float* y, void* stream);
+
 /* Backward of that layer for the training side (reference train_tgtcs.py:218-309 backpropagates through the NeRF MLPs):
  *   dx[M,K] = dy[M,N] . W[N,K]        (NULL to skip)
  *   dW[N,K] = dy^T . x,  db[N] = column sums of dy   (NULL to skip either)

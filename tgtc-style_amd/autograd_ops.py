@@ -16,6 +16,22 @@ def _ws(nbytes, device):
     return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
 
 
+_halves = {}      # id(parameter) -> (data_ptr, version, hi, lo): the weight split once per optimiser step
+
+
+def _split(weight, w):
+    key = id(weight)
+    hit = _halves.get(key)
+    if hit is None or hit[0] != weight.data_ptr() or hit[1] != weight._version:
+        lib = hip.load()
+        hi = torch.empty(w.numel(), dtype=torch.float16, device=w.device)
+        lo = torch.empty_like(hi)
+        hip.check(lib.tgtc_s2d_split(hip.ptr(w), w.numel(), hip.ptr(hi), hip.ptr(lo), hip.stream()))
+        hit = (weight.data_ptr(), weight._version, hi, lo)
+        _halves[key] = hit
+    return hit[2], hit[3]
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu, precision):
@@ -25,8 +41,9 @@ class _Linear(torch.autograd.Function):
         M, K = x.shape
         N = w.shape[0]
         y = torch.empty(M, N, device=x.device)
-        hip.check(lib.tgtc_s2d_linear(hip.ptr(x), M, K, hip.ptr(w), hip.ptr(b), N, int(relu), hip.PRECISIONS[precision], hip.ptr(y),
-                                      hip.stream()))
+        hi, lo = _split(weight, w) if K % 4 == 0 else (None, None)
+        hip.check(lib.tgtc_s2d_linear_pre(hip.ptr(x), M, K, hip.ptr(w), hip.ptr(hi), hip.ptr(lo), hip.ptr(b), N, int(relu),
+                                          hip.PRECISIONS[precision], hip.ptr(y), hip.stream()))
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.relu, ctx.precision, ctx.has_bias = relu, precision, bias is not None
         return y

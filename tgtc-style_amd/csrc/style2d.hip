@@ -618,6 +618,33 @@ __global__ void __launch_bounds__(256) transpose_ld_kernel(const float* __restri
     for (int j = ty; j < 32; j += 8)
         if (bx + j < cols && by + tx < rows) out[(long long)(bx + j) * ld_out + by + tx] = tile[tx][j] * (scale ? *scale : 1.0f);
 }
+// fp32 -> fp16 hi / lo halves (the GEMM's pre-split B operand)
+__global__ void __launch_bounds__(256) split_kernel(const float* __restrict__ in, long long n, half_t* __restrict__ hi,
+                                                    half_t* __restrict__ lo) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = in[i];
+    const half_t h = (half_t)v;
+    hi[i] = h, lo[i] = (half_t)(v - (float)h);
+}
+// transpose_ld_kernel writing the halves instead: [rows, cols] fp32 -> hi / lo [cols, ld_out] fp16
+__global__ void __launch_bounds__(256) transpose_ld_half_kernel(const float* __restrict__ in, long long rows, int cols,
+                                                                half_t* __restrict__ hi, half_t* __restrict__ lo, long long ld_out) {
+    __shared__ float tile[32][33];
+    const long long by = (long long)blockIdx.y * 32;
+    const int bx = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (by + j < rows && bx + tx < cols) tile[j][tx] = in[(by + j) * cols + bx + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (bx + j < cols && by + tx < rows) {
+            const float v = tile[tx][j];
+            const half_t h = (half_t)v;
+            const long long o = (long long)(bx + j) * ld_out + by + tx;
+            hi[o] = h, lo[o] = (half_t)(v - (float)h);
+        }
+}
 // Gradients arrive many orders of magnitude below 1 (a mean over the batch sits in front of them), below the range in which
 // an fp16 hi/lo split is exact.  They are rescaled by a power of two -- largest magnitude to ~2^10 -- on their way into the
 // GEMM operands and the products scaled back; the factor never leaves the device.
@@ -811,8 +838,10 @@ static int launch_gemm(const tgtc_style2d* h, AL al, DenseRows bl, GemmOut out, 
         else gemm_kernel<AL, false, true, 4><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
     } else {
         // weights of this handle: take their pre-split halves (8-byte aligned quads need K, ld and the offset multiples of 4)
-        bool pre = false;
+        bool pre = bl.h16 != nullptr && K % 4 == 0 && bl.ld % 4 == 0 && bl.batch_stride % 4 == 0;   // halves handed in by the caller
+        if (!pre) bl.h16 = bl.l16 = nullptr;
         if constexpr (std::is_same<AL, DenseRows>::value || std::is_same<AL, ConvNHWC>::value) {
+            if (!pre)
             for (const auto& r : h->pre)
                 if (bl.p >= r.base && bl.p < r.base + r.n && K % 4 == 0 && bl.ld % 4 == 0 && bl.batch_stride % 4 == 0 && (bl.p - r.base) % 4 == 0) {
                     bl.h16 = r.hi16 + (bl.p - r.base), bl.l16 = r.lo16 + (bl.p - r.base), pre = true;
@@ -1311,6 +1340,32 @@ extern "C" int tgtc_s2d_linear(const float* x, int64_t M, int K, const float* W,
     return linear(&h, x, K, (int)M, K, W, b, N, y, N, nullptr, relu, as_stream(stream));
 }
 
+// The same layer with the weight also given as fp16 hi / lo halves (tgtc_s2d_split; K a multiple of 4), which the GEMM
+// loads without converting: for callers that apply one weight to many batches (the training side re-splits after each
+// optimiser step).
+extern "C" int tgtc_s2d_split(const float* w, int64_t n, void* hi, void* lo, void* stream) {
+    TGTC_REQUIRE(n >= 0, "s2d_split: bad size");
+    if (n == 0) return TGTC_OK;
+    TGTC_REQUIRE(w && hi && lo, "s2d_split: null pointer");
+    split_kernel<<<(unsigned)((n + 255) / 256), 256, 0, as_stream(stream)>>>(w, n, static_cast<half_t*>(hi), static_cast<half_t*>(lo));
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
+}
+
+extern "C" int tgtc_s2d_linear_pre(const float* x, int64_t M, int K, const float* W, const void* W_hi, const void* W_lo,
+                                   const float* b, int N, int relu, int precision, float* y, void* stream) {
+    TGTC_REQUIRE(M >= 0 && M < 0x7fffffffLL && K > 0 && N > 0, "s2d_linear_pre: bad shape");
+    TGTC_REQUIRE(precision == TGTC_PREC_FP16 || precision == TGTC_PREC_FP16X3, "s2d_linear_pre: unknown precision %d", precision);
+    if (M == 0) return TGTC_OK;
+    TGTC_REQUIRE(x && W && y, "s2d_linear_pre: null pointer");
+    tgtc_style2d h;
+    h.precision = precision;
+    DenseRows al{x, K, 0, (int)M, K}, bl{W, K, 0, N, K};
+    if (W_hi && W_lo && K % 4 == 0) bl.h16 = static_cast<const half_t*>(W_hi), bl.l16 = static_cast<const half_t*>(W_lo);
+    GemmOut out{y, N, 1, 0, b, nullptr, 1.0f, relu};
+    return launch_gemm<DenseRows, false>(&h, al, bl, out, (int)M, N, K, 1, as_stream(stream));
+}
+
 // split of the sample dimension for dW = dy^T . x: enough batches to fill the chip with 64x64 tiles, 32-aligned
 static void backward_split(int64_t M, int K, int N, int& nsplit, int64_t& mc) {
     const long long tiles = (long long)((N + 63) / 64) * ((K + 63) / 64);
@@ -1361,6 +1416,12 @@ extern "C" int tgtc_s2d_linear_backward(const float* x, const float* dy, const f
         transpose_ld_kernel<<<g, 256, 0, st>>>(W, N, K, WT, N);
         TGTC_LAUNCH_CHECK();
         DenseRows al{dys, N, 0, (int)M, N}, bl{WT, N, 0, K, N};
+        if (N % 4 == 0) {   // the weight as pre-split halves (no conversion in the GEMM loop)
+            half_t* w16 = reinterpret_cast<half_t*>(part);   // (>= N*K floats; the dW partials come later on the stream)
+            split_kernel<<<(unsigned)(((long long)K * N + 255) / 256), 256, 0, st>>>(WT, (long long)K * N, w16, w16 + (size_t)K * N);
+            TGTC_LAUNCH_CHECK();
+            bl.h16 = w16, bl.l16 = w16 + (size_t)K * N;
+        }
         GemmOut out{dx, K, 1, 0, nullptr, nullptr, 1.0f, 0};
         out.alpha_dev = sc + 2;
         TGTC_TRY((launch_gemm<DenseRows, false>(&h, al, bl, out, (int)M, K, N, 1, st)));
@@ -1373,12 +1434,18 @@ extern "C" int tgtc_s2d_linear_backward(const float* x, const float* dy, const f
         TGTC_LAUNCH_CHECK();
     }
     if (dW) {   // dW[N,K] = sum over sample chunks of (s*dy)^T[N, chunk] . xT[K, chunk]^T, chunks as GEMM batches, times 1/s
-        if (mpad > M)
-            TGTC_HIP_CHECK(hipMemset2DAsync(xT + M, (size_t)mpad * sizeof(float), 0, (size_t)(mpad - M) * sizeof(float), K, st));
+        // x^T straight into fp16 hi / lo halves [K, mpad] each (the GEMM's pre-split B operand), pad columns cleared
+        half_t* xh = reinterpret_cast<half_t*>(xT);
+        half_t* xl = xh + (size_t)K * mpad;
+        if (mpad > M) {
+            TGTC_HIP_CHECK(hipMemset2DAsync(xh + M, (size_t)mpad * sizeof(half_t), 0, (size_t)(mpad - M) * sizeof(half_t), K, st));
+            TGTC_HIP_CHECK(hipMemset2DAsync(xl + M, (size_t)mpad * sizeof(half_t), 0, (size_t)(mpad - M) * sizeof(half_t), K, st));
+        }
         const dim3 g((K + 31) / 32, (unsigned)((M + 31) / 32));
-        transpose_ld_kernel<<<g, 256, 0, st>>>(x, M, K, xT, mpad);
+        transpose_ld_half_kernel<<<g, 256, 0, st>>>(x, M, K, xh, xl, mpad);
         TGTC_LAUNCH_CHECK();
         DenseRows al{dyT, mpad, mc, N, (int)mc}, bl{xT, mpad, mc, K, (int)mc};
+        bl.h16 = xh, bl.l16 = xl;
         GemmOut out{nsplit > 1 ? part : dW, K, 1, (long long)N * K, nullptr, nullptr, 1.0f, 0};
         out.alpha_dev = sc + 2;
         TGTC_TRY((launch_gemm<DenseRows, false>(&h, al, bl, out, N, K, (int)mc, nsplit, st)));

@@ -41,6 +41,8 @@ SIGNATURES = {
                             c_void_p, c_void_p],
     "tgtc_s2d_mean_std": [c_void_p, c_int, c_int64, c_float, c_void_p, c_void_p, c_void_p],
     "tgtc_s2d_linear": [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "tgtc_s2d_split": [c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
+    "tgtc_s2d_linear_pre": [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "tgtc_s2d_linear_backward_workspace_bytes": [c_int64, c_int, c_int],
     "tgtc_s2d_linear_backward": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                  c_void_p, c_void_p, c_void_p],
