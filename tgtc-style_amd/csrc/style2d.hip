@@ -155,10 +155,12 @@ __device__ __forceinline__ void put4(half_t* hi, half_t* lo, const float (&v)[4]
 // picks; a [2500,512] projection is only 20x4 tiles of 128x128 on 256 CUs).
 // B_PRE: the B rows come pre-split (DenseRows::h16 / l16, K a multiple of 4): two 8-byte loads per quad go straight to LDS,
 // no conversion in the loop.
-template <class AL, bool SPLIT, bool B_KMAJOR, int WT, bool B_PRE = false>
+// A_PRE: the same for a DenseRows A operand whose halves the producer wrote (the training side's gradients).
+template <class AL, bool SPLIT, bool B_KMAJOR, int WT, bool B_PRE = false, bool A_PRE = false>
 __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut out, int M, int N, int K) {
     constexpr int NP = SPLIT ? 2 : 1;
     static_assert(!(B_PRE && B_KMAJOR), "pre-split weights are row operands");
+    static_assert(!A_PRE || std::is_same<AL, DenseRows>::value, "pre-split A operands are dense rows");
     constexpr int BM = 32 * WT, BN = 32 * WT;
     static_assert(!B_KMAJOR || WT == 4, "the k-major B loader is written for 128-wide tiles");
     __shared__ __attribute__((aligned(16))) half_t sA[NP][BM][LDK];
@@ -170,6 +172,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
     al.p += (long long)blockIdx.z * al.batch_stride;
     bl.p += (long long)blockIdx.z * bl.batch_stride;
     if constexpr (B_PRE) bl.h16 += (long long)blockIdx.z * bl.batch_stride, bl.l16 += (long long)blockIdx.z * bl.batch_stride;
+    if constexpr (A_PRE) al.h16 += (long long)blockIdx.z * al.batch_stride, al.l16 += (long long)blockIdx.z * al.batch_stride;
     out.C += (long long)blockIdx.z * out.batch_stride;
     if (out.res) out.res += (long long)blockIdx.z * out.batch_stride;
     if (out.bias) out.bias += (long long)blockIdx.z * out.bias_batch_stride;
@@ -186,12 +189,20 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
     // k-major B: thread covers k = (tid>>5) + 8i, n-quad (tid&31)*4
     const int bk = tid >> 5, bnq = (tid & 31) * 4;
 
-    float ra[WT][4], rb[B_PRE ? 1 : WT][4];
-    uint2 rbh[B_PRE ? WT : 1], rbl[B_PRE ? WT : 1];
+    float ra[A_PRE ? 1 : WT][4], rb[B_PRE ? 1 : WT][4];
+    uint2 rbh[B_PRE ? WT : 1], rbl[B_PRE ? WT : 1], rah[A_PRE ? WT : 1], ral[A_PRE ? WT : 1];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
-            al.load4(actx[i], k0, skq, ra[i]);
+            if constexpr (A_PRE) {
+                const int row = m0 + srow + 32 * i, k = k0 + skq;
+                const bool ok = row < al.rows && k < al.K;
+                const long long o = (long long)row * al.ld + k;
+                rah[i] = ok ? *reinterpret_cast<const uint2*>(al.h16 + o) : uint2{0u, 0u};
+                if constexpr (SPLIT) ral[i] = ok ? *reinterpret_cast<const uint2*>(al.l16 + o) : uint2{0u, 0u};
+            } else {
+                al.load4(actx[i], k0, skq, ra[i]);
+            }
             if constexpr (B_PRE) {
                 const int row = n0 + srow + 32 * i, k = k0 + skq;
                 const bool ok = row < bl.rows && k < bl.K;     // K % 4 == 0: a quad is inside or outside as a whole
@@ -211,7 +222,12 @@ __global__ void __launch_bounds__(256) gemm_kernel(AL al, DenseRows bl, GemmOut 
     auto stash = [&]() {
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
-            put4<SPLIT>(&sA[0][srow + 32 * i][skq], &sA[NP - 1][srow + 32 * i][skq], ra[i]);
+            if constexpr (A_PRE) {
+                *reinterpret_cast<uint2*>(&sA[0][srow + 32 * i][skq]) = rah[i];
+                if constexpr (SPLIT) *reinterpret_cast<uint2*>(&sA[1][srow + 32 * i][skq]) = ral[i];
+            } else {
+                put4<SPLIT>(&sA[0][srow + 32 * i][skq], &sA[NP - 1][srow + 32 * i][skq], ra[i]);
+            }
             if constexpr (B_PRE) {
                 *reinterpret_cast<uint2*>(&sB[0][srow + 32 * i][skq]) = rbh[i];
                 if constexpr (SPLIT) *reinterpret_cast<uint2*>(&sB[1][srow + 32 * i][skq]) = rbl[i];
@@ -618,6 +634,16 @@ __global__ void __launch_bounds__(256) transpose_ld_kernel(const float* __restri
     for (int j = ty; j < 32; j += 8)
         if (bx + j < cols && by + tx < rows) out[(long long)(bx + j) * ld_out + by + tx] = tile[tx][j] * (scale ? *scale : 1.0f);
 }
+// out halves = split(gate ? in * scale : 0): the scaled, ReLU-gated gradient as a pre-split GEMM operand
+__global__ void __launch_bounds__(256) scale_split_kernel(const float* __restrict__ in, long long n, const float* __restrict__ sc,
+                                                          const float* __restrict__ gate, half_t* __restrict__ hi,
+                                                          half_t* __restrict__ lo) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = (gate && !(gate[i] > 0.0f)) ? 0.0f : in[i] * sc[1];
+    const half_t h = (half_t)v;
+    hi[i] = h, lo[i] = (half_t)(v - (float)h);
+}
 // fp32 -> fp16 hi / lo halves (the GEMM's pre-split B operand)
 __global__ void __launch_bounds__(256) split_kernel(const float* __restrict__ in, long long n, half_t* __restrict__ hi,
                                                     half_t* __restrict__ lo) {
@@ -629,17 +655,22 @@ __global__ void __launch_bounds__(256) split_kernel(const float* __restrict__ in
 }
 // transpose_ld_kernel writing the halves instead: [rows, cols] fp32 -> hi / lo [cols, ld_out] fp16
 __global__ void __launch_bounds__(256) transpose_ld_half_kernel(const float* __restrict__ in, long long rows, int cols,
-                                                                half_t* __restrict__ hi, half_t* __restrict__ lo, long long ld_out) {
+                                                                half_t* __restrict__ hi, half_t* __restrict__ lo, long long ld_out,
+                                                                const float* __restrict__ scale = nullptr,
+                                                                const float* __restrict__ gate = nullptr) {
     __shared__ float tile[32][33];
     const long long by = (long long)blockIdx.y * 32;
     const int bx = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int j = ty; j < 32; j += 8)
-        if (by + j < rows && bx + tx < cols) tile[j][tx] = in[(by + j) * cols + bx + tx];
+        if (by + j < rows && bx + tx < cols) {
+            const long long o = (by + j) * cols + bx + tx;
+            tile[j][tx] = (gate && !(gate[o] > 0.0f)) ? 0.0f : in[o];
+        }
     __syncthreads();
     for (int j = ty; j < 32; j += 8)
         if (bx + j < cols && by + tx < rows) {
-            const float v = tile[tx][j];
+            const float v = tile[tx][j] * (scale ? *scale : 1.0f);
             const half_t h = (half_t)v;
             const long long o = (long long)(bx + j) * ld_out + by + tx;
             hi[o] = h, lo[o] = (half_t)(v - (float)h);
@@ -679,14 +710,15 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restri
     for (int z = 0; z < nsplit; ++z) s += part[(long long)z * n + i];
     out[i] = s;
 }
-// out[row] += scale * sum of in[row][chunk]: one workgroup per (row, chunk of `mc` elements), out pre-zeroed
-__global__ void __launch_bounds__(256) rowsum_kernel(const float* __restrict__ in, long long n, long long ld, long long mc,
-                                                     float* __restrict__ out, const float* __restrict__ scale = nullptr) {
+// out[row] += scale * sum of (hi + lo)[row][chunk]: one workgroup per (row, chunk of `mc` elements), out pre-zeroed
+__global__ void __launch_bounds__(256) rowsum_kernel(const half_t* __restrict__ hi, const half_t* __restrict__ lo, long long n,
+                                                     long long ld, long long mc, float* __restrict__ out,
+                                                     const float* __restrict__ scale = nullptr) {
     __shared__ float red[4];
-    const long long lo = (long long)blockIdx.y * mc, hi = min(n, lo + mc);
-    const float* row = in + (long long)blockIdx.x * ld;
+    const long long b = (long long)blockIdx.y * mc, e = min(n, b + mc);
+    const long long r0 = (long long)blockIdx.x * ld;
     float s = 0.0f;
-    for (long long i = lo + threadIdx.x; i < hi; i += 256) s += row[i];
+    for (long long i = b + threadIdx.x; i < e; i += 256) s += (float)hi[r0 + i] + (float)lo[r0 + i];
 #pragma unroll
     for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -856,6 +888,21 @@ static int launch_gemm(const tgtc_style2d* h, AL al, DenseRows bl, GemmOut out, 
             if (split) gemm_kernel<AL, true, false, WT, PRE><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
             else gemm_kernel<AL, false, false, WT, PRE><<<grid, 256, 0, st>>>(al, bl, out, M, N, K);
         };
+        if constexpr (std::is_same<AL, DenseRows>::value) {
+            // both operands pre-split (the training side's backward GEMMs): nothing converts in the loop
+            if (pre && al.h16 && K % 4 == 0 && al.ld % 4 == 0 && al.batch_stride % 4 == 0) {
+                const dim3 grid1((M + 31) / 32, (N + 31) / 32, batch), grid2((M + 63) / 64, (N + 63) / 64, batch);
+                if (mid < 400) {
+                    if (split) gemm_kernel<AL, true, false, 1, true, true><<<grid1, 256, 0, st>>>(al, bl, out, M, N, K);
+                    else gemm_kernel<AL, false, false, 1, true, true><<<grid1, 256, 0, st>>>(al, bl, out, M, N, K);
+                } else {
+                    if (split) gemm_kernel<AL, true, false, 2, true, true><<<grid2, 256, 0, st>>>(al, bl, out, M, N, K);
+                    else gemm_kernel<AL, false, false, 2, true, true><<<grid2, 256, 0, st>>>(al, bl, out, M, N, K);
+                }
+                TGTC_LAUNCH_CHECK();
+                return TGTC_OK;
+            }
+        }
         if constexpr (std::is_same<AL, DenseRows>::value || std::is_same<AL, ConvNHWC>::value) {
             if (pre) {
                 if (mid < 400) go(ic<1>{}, std::true_type{});
@@ -1410,12 +1457,17 @@ extern "C" int tgtc_s2d_linear_backward(const float* x, const float* dy, const f
     grad_scale_kernel<<<1, 1, 0, st>>>(sc);
     TGTC_LAUNCH_CHECK();
     if (dx) {   // dx[M,K] = dy[M,N] . W[N,K]: a linear layer on s*dy whose weight is W^T [K,N], scaled back by 1/s
-        scale_copy_kernel<<<(unsigned)((mn + 255) / 256), 256, 0, st>>>(dy, mn, sc, dys, relu_y);
+        half_t* dyh = reinterpret_cast<half_t*>(dys);      // s * gated dy as halves: [M,N] hi, then lo
+        half_t* dyl = dyh + (size_t)mn;
+        const bool a_pre = N % 4 == 0;
+        if (a_pre) scale_split_kernel<<<(unsigned)((mn + 255) / 256), 256, 0, st>>>(dy, mn, sc, relu_y, dyh, dyl);
+        else scale_copy_kernel<<<(unsigned)((mn + 255) / 256), 256, 0, st>>>(dy, mn, sc, dys, relu_y);
         TGTC_LAUNCH_CHECK();
         const dim3 g((K + 31) / 32, (N + 31) / 32);
         transpose_ld_kernel<<<g, 256, 0, st>>>(W, N, K, WT, N);
         TGTC_LAUNCH_CHECK();
         DenseRows al{dys, N, 0, (int)M, N}, bl{WT, N, 0, K, N};
+        if (a_pre) al.h16 = dyh, al.l16 = dyl;
         if (N % 4 == 0) {   // the weight as pre-split halves (no conversion in the GEMM loop)
             half_t* w16 = reinterpret_cast<half_t*>(part);   // (>= N*K floats; the dW partials come later on the stream)
             split_kernel<<<(unsigned)(((long long)K * N + 255) / 256), 256, 0, st>>>(WT, (long long)K * N, w16, w16 + (size_t)K * N);
@@ -1426,11 +1478,15 @@ extern "C" int tgtc_s2d_linear_backward(const float* x, const float* dy, const f
         out.alpha_dev = sc + 2;
         TGTC_TRY((launch_gemm<DenseRows, false>(&h, al, bl, out, (int)M, K, N, 1, st)));
     }
+    half_t* dth = reinterpret_cast<half_t*>(dyT);      // (s * gated dy)^T as halves [N, mpad] each, zero padded
+    half_t* dtl = dth + (size_t)N * mpad;
     if (dW || db) {
-        if (mpad > M)   // only the pad columns: the transpose writes the rest
-            TGTC_HIP_CHECK(hipMemset2DAsync(dyT + M, (size_t)mpad * sizeof(float), 0, (size_t)(mpad - M) * sizeof(float), N, st));
+        if (mpad > M) {   // only the pad columns: the transpose writes the rest
+            TGTC_HIP_CHECK(hipMemset2DAsync(dth + M, (size_t)mpad * sizeof(half_t), 0, (size_t)(mpad - M) * sizeof(half_t), N, st));
+            TGTC_HIP_CHECK(hipMemset2DAsync(dtl + M, (size_t)mpad * sizeof(half_t), 0, (size_t)(mpad - M) * sizeof(half_t), N, st));
+        }
         const dim3 g((N + 31) / 32, (unsigned)((M + 31) / 32));
-        transpose_ld_kernel<<<g, 256, 0, st>>>(dy, M, N, dyT, mpad, dW ? sc + 1 : nullptr, relu_y);
+        transpose_ld_half_kernel<<<g, 256, 0, st>>>(dy, M, N, dth, dtl, mpad, sc + 1, relu_y);
         TGTC_LAUNCH_CHECK();
     }
     if (dW) {   // dW[N,K] = sum over sample chunks of (s*dy)^T[N, chunk] . xT[K, chunk]^T, chunks as GEMM batches, times 1/s
@@ -1445,6 +1501,7 @@ extern "C" int tgtc_s2d_linear_backward(const float* x, const float* dy, const f
         transpose_ld_half_kernel<<<g, 256, 0, st>>>(x, M, K, xh, xl, mpad);
         TGTC_LAUNCH_CHECK();
         DenseRows al{dyT, mpad, mc, N, (int)mc}, bl{xT, mpad, mc, K, (int)mc};
+        al.h16 = dth, al.l16 = dtl;
         bl.h16 = xh, bl.l16 = xl;
         GemmOut out{nsplit > 1 ? part : dW, K, 1, (long long)N * K, nullptr, nullptr, 1.0f, 0};
         out.alpha_dev = sc + 2;
@@ -1457,7 +1514,7 @@ extern "C" int tgtc_s2d_linear_backward(const float* x, const float* dy, const f
     }
     if (db) {   // column sums of dy = row sums of its transpose (scaled by s when dW shares the buffer)
         TGTC_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)N * sizeof(float), st));
-        rowsum_kernel<<<dim3(N, nsplit), 256, 0, st>>>(dyT, M, mpad, mc, db, dW ? sc + 2 : nullptr);
+        rowsum_kernel<<<dim3(N, nsplit), 256, 0, st>>>(dth, dtl, M, mpad, mc, db, sc + 2);
         TGTC_LAUNCH_CHECK();
     }
     return TGTC_OK;
