@@ -248,16 +248,13 @@ def run_headline(args, precision, rank, world, dist):
     n_rays = H * W
     by_rays = args.sharding == "rays" and world > 1
     lo, hi = parallel.shard_range(n_rays, rank, world) if by_rays else (0, n_rays)
-    image = torch.empty(hi - lo, 4, device="cuda", dtype=torch.float32)
+    images = [torch.empty(hi - lo, 4, device="cuda", dtype=torch.float32) for _ in range(2)]
     timed = Timed(args.steps)
-
-    def gather_frames(local):
-        out = torch.empty(world * local.shape[0], 4, device="cuda", dtype=torch.float32)
-        if dist.get_backend() == "nccl":
-            dist.all_gather_into_tensor(out, local)     # RCCL over xGMI: [160000,4] fp32 per rank
-        else:
-            dist.all_gather(list(out.chunk(world)), local)
-        return out
+    # N > 1: the gather of frame i runs on a side stream while frame i+1 renders; two image buffers
+    gather = None
+    if world > 1:
+        gather = parallel.AsyncGather((lambda x: parallel.gather_rows(x, n_rays, rank, world, dist)) if by_rays
+                                      else (lambda x: parallel.gather_frames(x, world, dist)))
 
     def step(i, timed_idx=None):
         # frames sharding: every rank its own pose; rays sharding: all ranks the same pose, each its own pixel range
@@ -265,11 +262,15 @@ def run_headline(args, precision, rank, world, dist):
         o, d = utils.gen_rays(H, W, focal, pose, first_pixel=lo, n=hi - lo)
         render = lambda: renderer.render(o, d, N_COARSE, N_FINE, near=0., far=1.)
         out = timed.run(timed_idx, render) if timed_idx is not None else render()
+        image = images[i % 2]
+        if gather is not None:
+            gather.reusable(i)
         image[:, :3] = out["rgb"]
         image[:, 3] = out["t"]
-        if world == 1:
+        if gather is None:
             return image
-        return parallel.gather_rows(image, n_rays, rank, world, dist) if by_rays else gather_frames(image)
+        gather.submit(image)
+        return None
 
     for i in range(args.warmup):
         step(i)
@@ -280,6 +281,8 @@ def run_headline(args, precision, rank, world, dist):
     t0 = time.perf_counter()
     for i in range(args.steps):
         frame = step(args.warmup + i, timed_idx=i)
+    if gather is not None:
+        frame = gather.result()        # the last frame's gather is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -509,9 +509,73 @@ def g12_vae():
          state_keys=np.array(sorted(vae.state_dict().keys())))
 
 
+# ----------------------------------------------------------------------------- G13 files on disk
+def g13_files():
+    """Files as the REFERENCE writes them, kept as fixtures under tests/golden/files/ (a few KB each):
+
+    * geometry_00001.npz and geometry.npz -- written by the reference's own np.savez calls (rendering.py:73 and :81) during
+      a cal_geometry run on 3 frames of 6x8 pixels (the run of g10, inputs regenerable from seeds);
+    * 000500.tar, style_120500.tar, latent_120500.tar -- the reference's torch.save sites sit inside the closures of
+      train() (train_tgtcs.py:284-300, :503-517) and cannot be reached without a training run, so these hold what those
+      sites hold: the state dicts of the reference's OWN modules (width 8, so the files stay small) and of the optimisers
+      built the way train_tgtcs.py:37,54 builds them (after one step, so that they carry state), under the sites' keys;
+    * stylized_data.npz -- trans_test.py:179's keyword layout (a dict, a str, two float32 arrays) with the shapes of
+      trans_test.py:145,176-178; the driver around it needs torchvision and checkpoint files that do not exist offline.
+    """
+    import imageio
+    out_dir = os.path.join(HERE, "files")
+    os.makedirs(out_dir, exist_ok=True)
+    a = type("A", (Args,), {"N_samples": 64, "N_samples_fine": 64})
+    h, w, frames = 6, 8, 3
+    ro, rd = test_rays(frames * h * w, 1010)
+    coarse, fine = make_nerf(0, "coarse", a), make_nerf(1, "fine", a)
+    cps = np.tile(np.eye(4, dtype=np.float32)[None], (frames, 1, 1))
+    cps[:, 0, 3] = np.arange(frames)
+    ds = _FakeDataset(h, w, 0., 1., cps)
+    batches = [{"rays_o": torch.from_numpy(ro[i:i + 40]), "rays_d": torch.from_numpy(rd[i:i + 40])} for i in range(0, frames * h * w, 40)]
+    imageio.imwrite = lambda path, arr: None
+    try:
+        with tempfile.TemporaryDirectory() as tmp, torch.no_grad():
+            ref_rendering.cal_geometry(
+                model_forward=ref_utils.batchify(lambda **kw: coarse(**kw), 32), samp_func=ref_utils.sampling_pts_uniform,
+                dataloader=_FakeLoader(ds, batches), args=a, device="cpu", sv_path=tmp,
+                model_forward_fine=ref_utils.batchify(lambda **kw: fine(**kw), 32), samp_func_fine=ref_utils.sampling_pts_fine_torch)
+            for name in ("geometry_00001.npz", "geometry.npz"):
+                with open(os.path.join(tmp, name), "rb") as f, open(os.path.join(out_dir, name), "wb") as g:
+                    g.write(f.read())
+    finally:
+        del imageio.imwrite
+
+    small = type("S", (Args,), {"netwidth": 8, "netwidth_fine": 8, "lrate": 5e-4})
+    torch.manual_seed(13)
+    model, model_fine = ref_models.StyleNerf(args=small, mode='coarse'), ref_models.StyleNerf(args=small, mode='fine')
+    concat_model, style_model = ref_models.StyleMLP_before_concat(small), ref_models.StyleMLP_Wild_multilayers(small)
+    latents = ref_models.StyleLatents_variational(style_num=2, frame_num=3, latent_dim=32)
+    optimizer = torch.optim.Adam(params=list(model.parameters()) + list(model_fine.parameters()), lr=small.lrate, betas=(0.9, 0.999))
+    style_optimizer = torch.optim.Adam(params=list(style_model.parameters()) + list(concat_model.parameters()), lr=small.lrate, betas=(0.9, 0.999))
+    for opt, mods in ((optimizer, (model, model_fine)), (style_optimizer, (style_model, concat_model))):
+        sum((p ** 2).sum() for m in mods for p in m.parameters()).backward()
+        opt.step()
+    torch.save({'global_step': 500, 'model': model.state_dict(), 'model_fine': model_fine.state_dict(),
+                'optimizer': optimizer.state_dict(), 'style_optimizer': style_optimizer.state_dict()}, os.path.join(out_dir, "000500.tar"))
+    torch.save({'global_step': 120500, 'model': style_model.state_dict(), 'concat_model': concat_model.state_dict(),
+                'optimizer': style_optimizer.state_dict()}, os.path.join(out_dir, "style_120500.tar"))
+    torch.save({'global_step': 120500, 'train_set_1': latents.state_dict()}, os.path.join(out_dir, "latent_120500.tar"))
+
+    rng = np.random.default_rng(13)
+    style_feature = np.zeros([1, 1024], dtype=np.float32)
+    for _ in range(2):      # trans_test.py:176-178: one row appended per frame, then the mean over the appended rows
+        style_feature = np.append(style_feature, [rng.standard_normal(1024).astype(np.float32)], axis=0)
+    style_feature = np.sum(style_feature, axis=0, keepdims=True) / (style_feature.shape[0] - 1)
+    np.savez(os.path.join(out_dir, 'stylized_data'), style_names={"starry_night": 0}, style_paths="./style/starry_night.jpg",
+             style_images=rng.random((1, 16, 16, 3)).astype(np.float32), style_features=style_feature)
+    for name in sorted(os.listdir(out_dir)):
+        print("files/%-22s %8.1f KB" % (name, os.path.getsize(os.path.join(out_dir, name)) / 1024))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_rays, g2_coarse, g3_embed, g4_nerf, g5_composite, g6_fine, g7_style, g8_end_to_end, g9_style2d, g10_image,
-               g11_llff_poses, g12_vae):
+               g11_llff_poses, g12_vae, g13_files):
         if not only or fn.__name__.split("_")[0] in only:
             fn()

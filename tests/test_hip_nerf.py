@@ -255,6 +255,8 @@ def test_nerf_wide_kernel(M, monkeypatch):
     workgroup."""
     from tgtc_style_amd import hip
     lib = hip.load()
+    if not lib.tgtc_dev_kernels():
+        pytest.skip("development kernels are built by `make dev` only (TGTC_LIB=.../libtgtc_hip_dev.so)")
     monkeypatch.setenv("TGTC_NERF_WIDE", "1")
     rng = np.random.default_rng(100 + M)
     pts = torch.from_numpy(rng.uniform(-1.2, 1.2, (M, 3)))

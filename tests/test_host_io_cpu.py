@@ -91,6 +91,9 @@ def test_image_transforms_match_torchvision_semantics():
     # crop window larger than the image: centred, black outside
     c = np.asarray(trans_test._center_crop(img, 7, 9))
     assert c.shape == (7, 9, 3) and np.array_equal(c[1:6, 1:8], a) and not c[0].any() and not c[:, 0].any()
+    # an excess of 3 pixels: torchvision pads left / top (3 // 2) = 1 and right / bottom 2 (not the banker's-rounded -1.5 -> -2)
+    c = np.asarray(trans_test._center_crop(img, 8, 10))
+    assert c.shape == (8, 10, 3) and np.array_equal(c[1:6, 1:8], a) and not c[0].any() and not c[6:].any() and not c[:, 8:].any()
     s = trans_test.style_image_array.__doc__
     assert "512" in s
 
@@ -158,3 +161,79 @@ def test_checkpoint_files_round_trip(tmp_path):
     assert sorted(os.listdir(s2)) == ["decoder_iter_160000.pth", "embedding_iter_160000.pth", "transformer_iter_160000.pth"]
     assert sorted(torch.load(os.path.join(s2, "decoder_iter_160000.pth"))) == ["decoder", "step"]
     assert trans_test._newest(s2, "transformer").endswith("transformer_iter_160000.pth")
+
+
+FILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "files")
+
+
+def test_reference_written_checkpoint_files(tmp_path):
+    """tests/golden/files/*.tar hold the state dicts of the REFERENCE's own modules and optimisers under the keys of its
+    save sites (gen_golden.py g13_files; train_tgtcs.py:284-300, :503-517): checkpoints.py finds, reads and loads them
+    into this build's modules -- same key names, same shapes -- and a file this build writes has the same layout."""
+    import shutil
+    import torch
+    from tgtc_style_amd import checkpoints as ck, models
+
+    class A:
+        use_viewdir, act_type, embed_freq_coor, embed_freq_dir = True, "relu", 10, 4
+        netdepth = netdepth_fine = 8
+        netwidth = netwidth_fine = 8
+        style_D, vae_latent, precision = 8, 32, "fp16x3"
+
+    for f in ("000500.tar", "style_120500.tar", "latent_120500.tar"):
+        shutil.copy(os.path.join(FILES, f), tmp_path / f)
+    model, fine = models.StyleNerf(A, mode="coarse"), models.StyleNerf(A, mode="fine")
+    assert ck.load_nerf(str(tmp_path), model, fine) == 500                       # train_tgtcs.py:60-72
+    ref = torch.load(os.path.join(FILES, "000500.tar"), map_location="cpu")
+    assert sorted(ref) == ["global_step", "model", "model_fine", "optimizer", "style_optimizer"]
+    for name, m in (("model", model), ("model_fine", fine)):
+        assert list(m.state_dict()) == list(ref[name])
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, ref[name][k]), (name, k)
+    concat, style = models.StyleMLP_before_concat(A), models.StyleMLP_Wild_multilayers(A)
+    assert ck.load_style(str(tmp_path), style, concat) == 120500                 # :74-82
+    ref_s = torch.load(os.path.join(FILES, "style_120500.tar"), map_location="cpu")
+    assert sorted(ref_s) == ["concat_model", "global_step", "model", "optimizer"]
+    assert all(torch.equal(v, ref_s["model"][k]) for k, v in style.state_dict().items())
+    assert all(torch.equal(v, ref_s["concat_model"][k]) for k, v in concat.state_dict().items())
+    lat = models.StyleLatents_variational(style_num=2, frame_num=3, latent_dim=32)
+    assert ck.load_latents(str(tmp_path), lat)                                   # :139-146
+    ref_l = torch.load(os.path.join(FILES, "latent_120500.tar"), map_location="cpu")
+    assert sorted(ref_l) == ["global_step", "train_set_1"] and list(lat.state_dict()) == list(ref_l["train_set_1"])
+    assert torch.equal(lat.latents.detach(), ref_l["train_set_1"]["latents"])
+    # what this build writes has the reference file's layout, key for key (optimiser state dicts included)
+    opt = torch.optim.Adam(list(model.parameters()) + list(fine.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    sopt = torch.optim.Adam(list(style.parameters()) + list(concat.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    for o, mods in ((opt, (model, fine)), (sopt, (style, concat))):
+        sum((p ** 2).sum() for m in mods for p in m.parameters()).backward()
+        o.step()
+    mine = torch.load(ck.save_nerf(str(tmp_path / "w"), 500, model, fine, opt, sopt), map_location="cpu")
+    assert sorted(mine) == sorted(ref) and list(mine["model"]) == list(ref["model"])
+    assert sorted(mine["optimizer"]) == sorted(ref["optimizer"]) and \
+        [g["params"] for g in mine["optimizer"]["param_groups"]] == [g["params"] for g in ref["optimizer"]["param_groups"]]
+    mine_s = torch.load(ck.save_style(str(tmp_path / "w"), 120500, style, concat, sopt), map_location="cpu")
+    assert sorted(mine_s) == sorted(ref_s) and list(mine_s["concat_model"]) == list(ref_s["concat_model"])
+    mine_l = torch.load(ck.save_latents(str(tmp_path / "w"), 120500, lat), map_location="cpu")
+    assert sorted(mine_l) == sorted(ref_l) and list(mine_l["train_set_1"]) == list(ref_l["train_set_1"])
+
+
+def test_reference_written_npz_files(tmp_path):
+    """geometry_00001.npz / geometry.npz as the reference's cal_geometry wrote them (rendering.py:73,81) and a
+    stylized_data.npz in trans_test.py:179's layout: names, dtypes and shapes this build's readers and writers rely on."""
+    import shutil
+    g1 = np.load(os.path.join(FILES, "geometry_00001.npz"))
+    assert sorted(g1.files) == ["coor_map", "cps", "far", "hwf", "near"]
+    assert g1["coor_map"].shape == (6, 8, 3) and g1["coor_map"].dtype == np.float32
+    assert g1["cps"].shape == (4, 4) and g1["cps"].dtype == np.float32 and float(g1["cps"][0, 3]) == 1.0   # frame 1's pose
+    assert g1["hwf"].shape == (3,) and float(g1["hwf"][0]) == 6 and float(g1["hwf"][1]) == 8
+    assert float(g1["near"]) == 0.0 and float(g1["far"]) == 1.0
+    g = np.load(os.path.join(FILES, "geometry.npz"))
+    assert sorted(g.files) == sorted(g1.files) and g["coor_map"].shape == (3, 6, 8, 3) and g["cps"].shape == (3, 4, 4)
+    assert np.array_equal(g["coor_map"][1], g1["coor_map"])
+    dst = tmp_path / "data" / "stylized_gen_8.0"
+    dst.mkdir(parents=True)
+    shutil.copy(os.path.join(FILES, "stylized_data.npz"), dst / "stylized_data.npz")
+    d = trans_test.read_stylized_data(str(tmp_path / "data"), 8.0)                 # dataset.py:437-440
+    assert d["style_names"] == {"starry_night": 0} and str(d["style_paths"]) == "./style/starry_night.jpg"
+    assert d["style_images"].shape == (1, 16, 16, 3) and d["style_features"].shape == (1, 1024) and d["style_num"] == 1
+    assert d["style_features"].dtype == np.float32

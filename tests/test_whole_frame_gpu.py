@@ -51,23 +51,32 @@ def check_against_oracle(label, rgb, t, oracle, ro, rd, median_bound=1e-5):
     sample's sigma decides between an opaque and a transparent ray end, utils.py:367-369; a cdf step below 1e-5 switches
     the inverse-CDF interpolation, utils.py:604-605); on a whole frame a handful of rays sit on one, and there the
     fp32 reference itself jumps by more than the tolerance when the ray origin moves by 1e-7 relative.  Such rays are
-    identified by exactly that experiment on the ORACLE (never on the kernel) and must stay rare; every other ray
-    must meet 1e-3, and the median must sit at the precision mode's own level (fp32 rounding for fp16x3, the fp6
+    identified by exactly that experiment on the ORACLE (never on the kernel), must stay below 0.5 % and must agree to
+    1e-3 with one of the branches the oracle takes at the ray or 1e-7 beside it; every other ray must meet 1e-3, and the median must sit at the precision mode's own level (fp32 rounding for fp16x3, the fp6
     correction's ~1e-4 for a fine pass in fp16mx)."""
     ref = oracle(ro, rd)
-    moved = oracle(ro * (1.0 + 1e-7), rd)
-    unstable = torch.maximum((moved["rgb_fine"] - ref["rgb_fine"]).abs().max(-1).values,
-                             (moved["t_fine"] - ref["t_fine"]).abs()) > 1e-4
-    e = torch.maximum((rgb.cpu() - ref["rgb_fine"]).abs().max(-1).values, (t.cpu() - ref["t_fine"]).abs())
+    err_to = lambda o: torch.maximum((rgb.cpu() - o["rgb_fine"]).abs().max(-1).values, (t.cpu() - o["t_fine"]).abs())
+    e = err_to(ref)
+    unstable = torch.zeros_like(e, dtype=torch.bool)
+    e_branch = e.clone()           # distance to the NEAREST branch of the reference (ref itself or a 1e-7 neighbour)
+    for scale in (1.0 + 1e-7, 1.0 - 1e-7):
+        moved = oracle(ro * scale, rd)
+        unstable |= torch.maximum((moved["rgb_fine"] - ref["rgb_fine"]).abs().max(-1).values,
+                                  (moved["t_fine"] - ref["t_fine"]).abs()) > 1e-4
+        e_branch = torch.minimum(e_branch, err_to(moved))
     print("%s, %d rays vs oracle: max %.2e on the %d well-conditioned rays, median %.2e; %d rays on a discontinuity of the "
-          "reference (max %.2e there)" % (label, e.numel(), float(e[~unstable].max()), int((~unstable).sum()), float(e.median()),
-                                          int(unstable.sum()), float(e[unstable].max()) if bool(unstable.any()) else 0.0))
+          "reference (max %.2e to the oracle, %.2e to the nearest branch)" %
+          (label, e.numel(), float(e[~unstable].max()), int((~unstable).sum()), float(e.median()), int(unstable.sum()),
+           float(e[unstable].max()) if bool(unstable.any()) else 0.0, float(e_branch[unstable].max()) if bool(unstable.any()) else 0.0))
     assert float(e[~unstable].max()) <= 1e-3
-    assert float(e.median()) <= median_bound and int(unstable.sum()) <= max(2, e.numel() // 50)
+    # a ray on a discontinuity is not exempt from parity: it must land on one of the two branches the reference itself takes
+    # within 1e-7 of the ray, to the same 1e-3 -- a kernel bug in the Delta_last = 1e10 or denom < 1e-5 handling would not
+    assert not bool(unstable.any()) or float(e_branch[unstable].max()) <= 1e-3
+    assert float(e.median()) <= median_bound and int(unstable.sum()) <= max(2, e.numel() // 200)
 
 
-def spot_indices(H, W, per_band=176):
-    """>= 512 ray indices: the first two rows, two rows around the middle, and the LAST two rows of the frame."""
+def spot_indices(H, W, per_band=400):
+    """>= 1 200 ray indices: the first two rows, two rows around the middle, and the LAST two rows of the frame."""
     n = H * W
     bands = [(0, 2 * W), (n // 2 - W, n // 2 + W), (n - 2 * W, n)]
     idx = np.concatenate([np.linspace(lo, hi - 1, per_band).astype(np.int64) for lo, hi in bands] + [[n - 1]])
@@ -94,7 +103,7 @@ def test_whole_frame_plain(scene, precision):
     rgb, t = out["rgb"], out["t"]
     assert rgb.shape == (n, 3) and bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(t).all())
     idx = spot_indices(H, W)
-    assert idx.numel() >= 512 and int(idx[-1]) == n - 1
+    assert idx.numel() >= 1200 and int(idx[-1]) == n - 1
     sc, sf = T(synth.nerf_state(0)), T(synth.nerf_state(1))
     check_against_oracle("%s %dx%d plain %s" % (scene, W, H, precision), rgb[idx], t[idx],
                          lambda o, d: fields.render_plain(sc, sf, o, d, NC, NF), ro[idx].cpu(), rd[idx].cpu(),

@@ -16,19 +16,18 @@ def _ws(nbytes, device):
     return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
 
 
-_halves = {}      # id(parameter) -> (data_ptr, version, hi, lo): the weight split once per optimiser step
-
-
 def _split(weight, w):
-    key = id(weight)
-    hit = _halves.get(key)
+    """fp16 hi / lo halves of a weight, split once per optimiser step.  The cache entry is an attribute of the
+    Parameter itself -- it lives and dies with it (no id() reuse after a model is freed, nothing accumulates) -- and is
+    valid for one (storage, version) of the parameter."""
+    hit = getattr(weight, "_tgtc_halves", None)
     if hit is None or hit[0] != weight.data_ptr() or hit[1] != weight._version:
         lib = hip.load()
         hi = torch.empty(w.numel(), dtype=torch.float16, device=w.device)
         lo = torch.empty_like(hi)
         hip.check(lib.tgtc_s2d_split(hip.ptr(w), w.numel(), hip.ptr(hi), hip.ptr(lo), hip.stream()))
         hit = (weight.data_ptr(), weight._version, hi, lo)
-        _halves[key] = hit
+        weight._tgtc_halves = hit
     return hit[2], hit[3]
 
 

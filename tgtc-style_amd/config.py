@@ -41,6 +41,8 @@ EXTRA = {
     "synthetic": (None, False),        # no dataset / checkpoints: seeded weights + closed-form camera path
     "synthetic_hw": (int, 400),        # frame size of the synthetic scene
     "synthetic_frames": (int, 2),      # frames of the synthetic validation path
+    "latent_seed": (int, -1),          # seed of the latent draw when the table is initialised from the VAE (-1: unseeded, like
+                                       # the reference); under torchrun rank 0 draws and broadcasts either way
 }
 
 

@@ -160,11 +160,26 @@ struct SingleStreamMap {
 // joins the workgroup barrier and issues chunk v+SLOTS-1, which for v+SLOTS-1 >= PADC is chunk v+SLOTS-1-PADC of
 // the stream `next` points to.  Other vector-memory operations of the wave (ray loads, pixel stores) only make
 // the counted waits conservative: vmcnt retires in issue order.
+//
+// STAGGER (PERSIST only, -DTGTC_STAGGER=S, S > 0): the two waves of a SIMD (waves w and w + 4 of the workgroup) run the
+// same program and the ring barrier keeps them in phase -- both reach their LDS bursts, their epilogue VALU work and
+// their MFMA runs together (MI355X_MICROARCH.md, "Two waves per SIMD", item 9; profiles/r1_kernel_variants.md: the
+// barrier costs by keeping the SIMD-sharing waves in phase).  With a stagger, waves 4..7 ("late") execute every ring
+// boundary S register groups EARLIER in their program than waves 0..3: all eight waves still meet at the same barriers,
+// so behind each barrier the late waves are S groups behind their partners -- locked in anti-phase instead of in phase.
+// A late wave is still reading chunk v-1 when it joins the barrier "entering v", so the slot that barrier re-fills is
+// the one of chunk v-2: the look-ahead is SLOTS-2 chunks instead of SLOTS-1.
+#ifndef TGTC_STAGGER
+#define TGTC_STAGGER 0
+#endif
 template <class C, class Map, bool PERSIST = false, bool ASM_DMA = kAsmDmaDefault>
 struct WeightStream {
     static constexpr int NFRAG = Map::NFRAG;
     static constexpr int NCHUNK = (NFRAG + C::FPC - 1) / C::FPC;
     static constexpr int PADC = PERSIST ? (NCHUNK + C::SLOTS - 1) / C::SLOTS * C::SLOTS : NCHUNK;
+    static constexpr int STAG = PERSIST ? TGTC_STAGGER : 0;           // register groups by which waves 4..7 run behind
+    static constexpr int LOOK = C::SLOTS - 1 - (STAG > 0 ? 1 : 0);    // PERSIST: chunks issued ahead of the one being entered
+    bool late = false;                                                 // wave-uniform: wave >= 4 (STAG > 0 only)
     static_assert(!PERSIST || Map::NSEG == 1, "persistent streams are single segment");
     // LDS -> register staging in bursts of G fragments, double buffered: group g+1 is read while the
     // MFMAs of group g run.  (hipcc only ever emits `s_waitcnt lgkmcnt(0)` here, never a counted wait,
@@ -189,6 +204,7 @@ struct WeightStream {
 #pragma unroll
         for (int i = 0; i < Map::NSEG; ++i) src[i] = lane_src(streams[i], wave, lane);
         voff = wave * (C::GPC * 1024) + lane * 16;
+        late = STAG > 0 && wave >= C::NWAVES / 2;
         lds_wave = smem + wave * (C::GPC * 1024);
         lane_lo = opaque((lds_cptr)smem + lane * 16);
         lane_hi = opaque((lds_cptr)smem + (C::RING_BYTES > 65536 ? 65536 : 0) + lane * 16);
@@ -238,16 +254,16 @@ struct WeightStream {
     }
     // PERSIST, once per kernel: chunks 0 .. SLOTS-2 of the first stream (`next`), the state every enter() expects
     __device__ __forceinline__ void persist_prologue() const {
-        static_for<C::SLOTS - 1>([&](auto ch) { issue<PADC + decltype(ch)::value>(); });
+        static_for<LOOK>([&](auto ch) { issue<PADC + decltype(ch)::value>(); });
     }
     // PERSIST: enter the stream `next` points to (virtual chunk PADC of the pass that ends = chunk 0 of the new
     // one); the caller sets `next` again before the pass issues its first look-ahead into the following stream.
     __device__ __forceinline__ void enter_ring() {
         static_assert(PERSIST, "enter_ring() belongs to persistent streams");
-        wait_vmcnt<(C::SLOTS - 3) * C::GPC>();
+        wait_vmcnt<(LOOK - 2) * C::GPC>();
         __builtin_amdgcn_s_barrier();
         src[0] = next;
-        issue<C::SLOTS - 1>();
+        issue<LOOK>();
     }
     __device__ __forceinline__ void enter() {
         enter_ring();
@@ -292,9 +308,9 @@ struct WeightStream {
     template <int CH>
     __device__ __forceinline__ void boundary() const {
         if constexpr (PERSIST) {
-            wait_vmcnt<(C::SLOTS - 3) * C::GPC>();
+            wait_vmcnt<(LOOK - 2) * C::GPC>();
             __builtin_amdgcn_s_barrier();
-            issue<CH + C::SLOTS - 1>();
+            issue<CH + LOOK>();
         } else if constexpr (CH + 1 < NCHUNK) {
             constexpr int issued_last = (CH + C::SLOTS - 2 < NCHUNK - 1) ? CH + C::SLOTS - 2 : NCHUNK - 1;
             if constexpr (!(kAbl & 1)) wait_vmcnt<(issued_last - (CH + 1)) * C::GPC>();
@@ -311,7 +327,23 @@ struct WeightStream {
     __device__ __forceinline__ void get(half8& ah, half8& al) {
         constexpr int buf = (F / G) & 1, k = F % G;
         if constexpr (k == 0) {
-            if constexpr (F % C::FPC == 0 && F > 0) boundary<F / C::FPC>();
+            if constexpr (STAG == 0) {
+                if constexpr (F % C::FPC == 0 && F > 0) boundary<F / C::FPC>();
+            } else {
+                // waves 0..3 enter chunk c at its first fragment; waves 4..7 run the same boundary STAG groups earlier
+                // (at fragment c*FPC - STAG*G, or with the first group where that is negative)
+                static_assert(STAG * G <= C::FPC, "a late wave must not fall behind the chunk that is re-filled");
+                constexpr bool early_here = F % C::FPC == 0 && F > 0;
+                constexpr int FL = F + STAG * G;
+                constexpr bool late_here = F > 0 ? (FL % C::FPC == 0 && FL / C::FPC < NCHUNK) : (STAG * G == C::FPC && NCHUNK > 1);
+                if constexpr (early_here || late_here) {
+                    if (late) {
+                        if constexpr (late_here) boundary<(F > 0 ? FL / C::FPC : 1)>();
+                    } else {
+                        if constexpr (early_here) boundary<F / C::FPC>();
+                    }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < G; ++j) {  // a "use": the compiler's lgkmcnt wait lands HERE
                 asm volatile("" ::"v"(qh[buf][j]));

@@ -212,16 +212,32 @@ struct MxReader {
             }
         }
     }
+    // the boundaries waves 0..3 run on entering group QQ, run at the start of group Q (QQ = Q, or Q + STAG for waves 4..7)
+    template <int Q, int QQ, int NQ>
+    __device__ __forceinline__ void acquire_at() {
+        constexpr int prev = Q == 0 ? 0 : last_needed(QQ - 1, NQ);
+        constexpr int lo = prev + 1 > 1 ? prev + 1 : 1, hi = last_needed(QQ, NQ);
+        if constexpr (hi >= lo) {
+            // boundary<hi> re-fills the slot of chunk hi-1 (hi-2 with a stagger): groups already staged in registers whose
+            // bytes reach back into it must have their reads retired first
+            constexpr int refilled = hi - (Ring::STAG > 0 ? 1 : 0);
+            retire<Q, refilled, NQ>();
+            if constexpr (DEPTH > 1) retire<Q + 1, refilled, NQ>();
+            static_for<hi - lo + 1>([&](auto i) { ring.template boundary<lo + decltype(i)::value>(); });
+        }
+    }
+    template <int Q, int QQ, int NQ>
+    static constexpr bool acquires_at() {
+        constexpr int prev = Q == 0 ? 0 : last_needed(QQ - 1, NQ);
+        return last_needed(QQ, NQ) >= (prev + 1 > 1 ? prev + 1 : 1);
+    }
     template <int Q, int NQ>
     __device__ __forceinline__ void acquire() {
-        constexpr int prev = Q == 0 ? 0 : last_needed(Q - 1, NQ);
-        constexpr int lo = prev + 1 > 1 ? prev + 1 : 1, hi = last_needed(Q, NQ);
-        if constexpr (hi >= lo) {
-            // boundary<hi> re-fills the slot of chunk hi-1: groups already staged in registers whose bytes reach back into
-            // it must have their reads retired first
-            retire<Q, hi, NQ>();
-            if constexpr (DEPTH > 1) retire<Q + 1, hi, NQ>();
-            static_for<hi - lo + 1>([&](auto i) { ring.template boundary<lo + decltype(i)::value>(); });
+        if constexpr (Ring::STAG == 0) {
+            acquire_at<Q, Q, NQ>();
+        } else if constexpr (acquires_at<Q, Q, NQ>() || acquires_at<Q, Q + Ring::STAG, NQ>()) {
+            if (ring.late) acquire_at<Q, Q + Ring::STAG, NQ>();
+            else acquire_at<Q, Q, NQ>();
         }
     }
 };

@@ -258,6 +258,7 @@ TGTC_NERF_FP16_INSTANCES()
 TGTC_NERF_FP16_INSTANCES(extern)
 #endif
 
+#ifdef TGTC_DEV_KERNELS   // `make dev` only (libtgtc_hip_dev.so): development kernels are not part of the product library
 // mlp_nerf_wide.hip
 int nerf_wide_pack(const tgtc_linear* layers, bool split, std::vector<char>& out);
 int nerf_wide_launch(const tgtc_net* net, int in_mode, bool full, NerfArgs a, hipStream_t st);
@@ -268,6 +269,7 @@ static bool wide_selected() {
     const char* e = std::getenv("TGTC_NERF_WIDE");
     return e && e[0] == '1';
 }
+#endif
 
 template <int IN_MODE, bool FULL>
 static int dispatch_nerf(const tgtc_net* net, NerfArgs& a, hipStream_t st) {
@@ -285,8 +287,10 @@ static int dispatch_nerf(const tgtc_net* net, NerfArgs& a, hipStream_t st) {
         return nerf_mx_launch(IN_MODE, FULL, a, st);
     }
     if (net->precision == TGTC_PREC_FP16) return launch_nerf<CfgFast, IN_MODE, FULL>(a, st);
+#ifdef TGTC_DEV_KERNELS
     if (IN_MODE != IN_ENC && net->wide_off && !a.out_pts_enc && !a.out_dirs_enc && wide_selected())
         return nerf_wide_launch(net, IN_MODE, FULL, a, st);
+#endif
     return launch_nerf<CfgExact, IN_MODE, FULL>(a, st);
 #endif
 }
@@ -334,10 +338,12 @@ extern "C" int tgtc_nerf_create(const tgtc_linear* layers, int n_layers, int pre
         n_frags = p.n_frags;
     }
     std::vector<char> wide;
+#ifdef TGTC_DEV_KERNELS
     if (precision == TGTC_PREC_FP16X3) {
         const int rc = nerf_wide_pack(layers, true, wide);
         if (rc != TGTC_OK) return rc;
     }
+#endif
     tgtc_net* net = new tgtc_net();
     net->kind = 0, net->precision = precision;
     net->bias_bytes = kNerfBiasBytes;

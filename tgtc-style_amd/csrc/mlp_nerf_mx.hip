@@ -3,6 +3,10 @@
 #define TGTC_ASM_DMA 1  // see mlp_core.h lds_dma16
 #include "mlp_nerf_mx.h"
 
+#include <algorithm>
+#include <cstdlib>
+#include <initializer_list>
+
 #include "mlp_layouts.h"
 #include "mlp_mx.h"
 #include "mlp_nerf_mx_chain.h"
@@ -89,7 +93,61 @@ static int e2m3_encode(float x) {
     return c | (std::signbit(x) ? 32 : 0);
 }
 
-int nerf_mx_pack(const tgtc_linear* layers, std::vector<char>& bias_region, std::vector<char>& stream) {
+// Power-of-two cross-layer equalisation of the ReLU layers before packing.  The block-scaled corrections lose their
+// benefit with the dynamic range inside a 32-value block (activations) or a weight row (one exponent per row): a feature
+// whose activations run 64 x above its neighbours' flushes their fp6 codes, a consumer column 64 x below its row's maximum
+// loses its own.  A ReLU layer is positively homogeneous, so row i of layer l (and its bias) times 2^-k and column i of
+// every consumer of that feature times 2^k is the SAME function -- exactly, powers of two commute with every rounding --
+// and k_i = round(log2(rowmax_i / colmax_i) / 2) balances the two ranges feature by feature (what cross-layer range
+// equalisation does for integer quantisation).  Trained networks carry exactly this kind of per-feature scale freedom;
+// tests/probes/emu_mx_e2e.py measures what it is worth (profiles/r3_precision_emulation.md).  The remap layer's rows
+// stay as they are: base_remap is an output of the operator.
+struct EqualisedNerf {
+    std::vector<float> w[12], b[12];
+    tgtc_linear lin[12];
+};
+static void nerf_mx_equalise(const tgtc_linear* layers, EqualisedNerf& e) {
+    for (int l = 0; l < 12; ++l) {
+        e.w[l].assign(layers[l].weight, layers[l].weight + (size_t)layers[l].out_features * layers[l].in_features);
+        e.b[l].assign(layers[l].bias, layers[l].bias + layers[l].out_features);
+    }
+    struct Cons { int layer, col0; };
+    auto run = [&](int l, std::initializer_list<Cons> cons) {
+        const int n = layers[l].out_features, in = layers[l].in_features;
+        std::vector<int> k(n, 0);
+        for (int i = 0; i < n; ++i) {
+            float r1 = 0.0f, r2 = 0.0f;
+            for (int c = 0; c < in; ++c) r1 = std::fmax(r1, std::fabs(e.w[l][(size_t)i * in + c]));
+            for (const Cons& q : cons)
+                for (int r = 0; r < layers[q.layer].out_features; ++r)
+                    r2 = std::fmax(r2, std::fabs(e.w[q.layer][(size_t)r * layers[q.layer].in_features + q.col0 + i]));
+            if (r1 > 0.0f && r2 > 0.0f) k[i] = (int)std::nearbyint(0.5 * std::log2((double)r1 / (double)r2));
+        }
+        std::vector<int> sorted(k);
+        std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+        const int med = sorted[n / 2];   // only the spread matters: keep the layer's typical activation scale
+        for (int i = 0; i < n; ++i) {
+            const int ki = std::max(-8, std::min(8, k[i] - med));
+            if (ki == 0) continue;
+            const float down = std::ldexp(1.0f, -ki), up = std::ldexp(1.0f, ki);
+            for (int c = 0; c < in; ++c) e.w[l][(size_t)i * in + c] *= down;
+            e.b[l][i] *= down;
+            for (const Cons& q : cons)
+                for (int r = 0; r < layers[q.layer].out_features; ++r)
+                    e.w[q.layer][(size_t)r * layers[q.layer].in_features + q.col0 + i] *= up;
+        }
+    };
+    for (int l = 0; l < 7; ++l) run(l, {{l + 1, l + 1 == 5 ? 63 : 0}});   // layer 5 reads cat(pe(63), h) (models.py:98-99)
+    run(7, {{8, 0}, {9, 0}});                                              // sigma_layer and base_remap_layer read h
+    run(10, {{11, 0}});                                                    // rgb_layers.0 -> rgb_layers.1
+    for (int l = 0; l < 12; ++l) e.lin[l] = tgtc_linear{e.w[l].data(), e.b[l].data(), layers[l].out_features, layers[l].in_features};
+}
+
+int nerf_mx_pack(const tgtc_linear* layers_in, std::vector<char>& bias_region, std::vector<char>& stream) {
+    EqualisedNerf eq;
+    const char* no_eq = std::getenv("TGTC_MX_NO_EQUALISE");   // development: pack the weights as given
+    if (!(no_eq && no_eq[0] == '1')) nerf_mx_equalise(layers_in, eq);
+    const tgtc_linear* layers = (no_eq && no_eq[0] == '1') ? layers_in : eq.lin;
     const std::vector<LayerSpec> specs = nerf_specs(layers);
     const MxTable& T = kNerfMxTable;
     bias_region.assign(kNerfBiasBytes, 0);

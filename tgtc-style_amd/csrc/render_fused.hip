@@ -327,7 +327,7 @@ bool fused_render_supports(int prec_c, int prec_f, int n_coarse, int n_fine) {
     const bool pair = (prec_c == TGTC_PREC_FP16X3 && (prec_f == TGTC_PREC_FP16X3 || prec_f == TGTC_PREC_FP16_FP6)) ||
                       (prec_c == TGTC_PREC_FP16 && prec_f == TGTC_PREC_FP16);
     const int step = prec_c == TGTC_PREC_FP16 ? 32 : 16;   // tiles per pass x 16 samples
-    return pair && n_coarse >= 16 && n_coarse % step == 0 && (n_coarse + n_fine) % step == 0 && n_coarse <= 192 &&
+    return pair && n_fine >= 1 && n_coarse >= 16 && n_coarse % step == 0 && (n_coarse + n_fine) % step == 0 && n_coarse <= 192 &&
            n_coarse + n_fine <= kFusedMaxTotal;
 }
 

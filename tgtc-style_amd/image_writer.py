@@ -19,8 +19,12 @@ import torch
 
 
 def _encode(path, arr):
+    """Encode beside the target and rename into place: a run killed mid-encode leaves `<name>.tmp`, never a truncated
+    image that the resume-by-skipping of the drivers (rendering.py:267-270) would take for a finished frame."""
     from PIL import Image
-    Image.fromarray(arr).save(path)
+    tmp = path + ".tmp"
+    Image.fromarray(arr).save(tmp, format=os.path.splitext(path)[1][1:].upper().replace("JPG", "JPEG") or None)
+    os.replace(tmp, path)
 
 
 class ImageWriter:

@@ -215,8 +215,8 @@ class StyleMLP_before_concat(_Packed):
     def __init__(self, args):
         super().__init__()
         pe = args.embed_freq_coor * 3 * 2 + 3
-        if args.style_D != 8 or args.netwidth != 256 or pe != 63 or args.vae_latent != 32:
-            raise NotImplementedError("HIP kernels implement style_D=8, netwidth=256, embed_freq_coor=10, vae_latent=32")
+        # any shape can be built, loaded and saved (checkpoint files); the kernels behind forward() have one
+        self._unsupported = (args.style_D != 8 or args.netwidth != 256 or pe != 63 or args.vae_latent != 32)
         self.skips = [4]
         dims, dim = [], pe + args.vae_latent
         for i in range(args.style_D - 1):
@@ -228,7 +228,12 @@ class StyleMLP_before_concat(_Packed):
         self.layers = nn.ModuleList([nn.Linear(d, args.netwidth) for d in dims])
         self.precision = _precision_of(args, 'style')
 
+    def _require_supported(self):
+        if self._unsupported:
+            raise NotImplementedError("HIP kernels implement style_D=8, netwidth=256, embed_freq_coor=10, vae_latent=32")
+
     def _pack(self):
+        self._require_supported()
         return hip.style_create(concat_state=self.state_dict(), precision=self.precision)
 
     differentiable = False
@@ -241,6 +246,7 @@ class StyleMLP_before_concat(_Packed):
 
     def forward(self, **kwargs):
         x, latent = kwargs['x'], kwargs['latent']
+        self._require_supported()
         hip.require_gpu(x, latent)
         lib = hip.load()
         lead = x.shape[:-1]
@@ -269,8 +275,8 @@ class StyleMLP_Wild_multilayers(_Packed):
     def __init__(self, args):
         super().__init__()
         pe = args.embed_freq_coor * 3 * 2 + 3
-        if args.style_D != 8 or args.netwidth != 256 or pe != 63 or args.vae_latent != 32:
-            raise NotImplementedError("HIP kernels implement style_D=8, netwidth=256, embed_freq_coor=10, vae_latent=32")
+        # any shape can be built, loaded and saved (checkpoint files); the kernels behind forward() have one
+        self._unsupported = (args.style_D != 8 or args.netwidth != 256 or pe != 63 or args.vae_latent != 32)
         self.skips = [4]
         dims, dim = [], pe + 512 + args.vae_latent
         for i in range(args.style_D - 1):
@@ -282,7 +288,12 @@ class StyleMLP_Wild_multilayers(_Packed):
                                     [nn.Linear(args.netwidth + args.vae_latent, 3)])
         self.precision = _precision_of(args, 'style')
 
+    def _require_supported(self):
+        if self._unsupported:
+            raise NotImplementedError("HIP kernels implement style_D=8, netwidth=256, embed_freq_coor=10, vae_latent=32")
+
     def _pack(self):
+        self._require_supported()
         return hip.style_create(style_state=self.state_dict(), precision=self.precision)
 
     differentiable = False
@@ -295,6 +306,7 @@ class StyleMLP_Wild_multilayers(_Packed):
 
     def forward(self, **kwargs):
         x, conc, latent = kwargs['x'], kwargs['concated'], kwargs['latent']
+        self._require_supported()
         hip.require_gpu(x, conc, latent)
         lib = hip.load()
         lead = x.shape[:-1]
@@ -328,6 +340,7 @@ class StylePair(_Packed):
         self.precision = precision or concat_model.precision
 
     def _pack(self):
+        self.concat_model._require_supported(), self.style_model._require_supported()
         return hip.style_create(self.concat_model.state_dict(), self.style_model.state_dict(), self.precision)
 
     def packed(self):

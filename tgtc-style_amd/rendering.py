@@ -34,7 +34,7 @@ class RayRenderer:
         pc, pf = self.coarse.packed().precision, self.fine.packed().precision
         pair = (pc, pf) in (("fp16x3", "fp16x3"), ("fp16x3", "fp16mx"), ("fp16", "fp16"))
         step = 32 if pc == "fp16" else 16
-        return pair and nc >= 16 and nc % step == 0 and (nc + nf) % step == 0 and nc <= 192 and nc + nf <= 256
+        return pair and nf >= 1 and nc >= 16 and nc % step == 0 and (nc + nf) % step == 0 and nc <= 192 and nc + nf <= 256
 
     def _workspace(self, R, nc, nf, device):
         need = hip.load().tgtc_render_workspace_bytes(R, nc, nf)

@@ -64,6 +64,44 @@ def nerf_state(seed, depth=8, width=256, skips=(4,), use_viewdir=True, sigma_gai
     return sd
 
 
+def heavy_tailed(sd, seed, family):
+    """A NeRF state dict with heavy-tailed numbers (what trained MLPs look like; the seeded nets above are uniform).
+
+    'rows' (log-normal, sigma = 2 octaves) and 'outliers' (four features x64, two x1/64 per layer) use the
+    positive-scaling symmetry of a ReLU layer -- row i of layer l and its bias times s_i, column i of every consumer of
+    that feature times 1/s_i, s_i a power of two -- so the network computes the SAME function (the scene stays as well
+    conditioned as the base one) while per-feature activation ranges and per-column weight ranges spread by up to 2^12.
+    'elements' multiplies every trunk weight by its own log-normal factor: a different function (callers re-centre the
+    density head, see tests/probes/emu_mx_e2e.py recalibrate_sigma)."""
+    if family == "base":
+        return sd
+    rng = np.random.default_rng(1000 + seed)
+    sd = {k: v.copy() for k, v in sd.items()}
+    if family == "elements":
+        for i in range(1, 8):
+            w = sd["net.base_layers.%d.weight" % i]
+            f = np.exp(rng.normal(0.0, 0.6, w.shape)).astype(np.float32)
+            sd["net.base_layers.%d.weight" % i] = w * f / np.float32(math.exp(0.18))   # E[f] = e^0.18: keep the activation scale
+        return sd
+    if family not in ("rows", "outliers"):
+        raise ValueError(family)
+    for i in range(8):
+        n = 256
+        if family == "rows":
+            s = np.exp2(np.rint(rng.normal(0.0, 2.0, n))).astype(np.float32)
+        else:
+            s = np.ones(n, np.float32)
+            idx = rng.choice(n, 6, replace=False)
+            s[idx[:4]], s[idx[4:]] = 64.0, 1.0 / 64.0
+        name = "net.base_layers.%d" % i
+        sd[name + ".weight"] = sd[name + ".weight"] * s[:, None]
+        sd[name + ".bias"] = sd[name + ".bias"] * s
+        cons = [("net.base_layers.%d" % (i + 1), 63 if i == 4 else 0)] if i < 7 else [("net.sigma_layer", 0), ("net.base_remap_layer", 0)]
+        for c, c0 in cons:       # layer 5 reads cat(pe(63), h) (models.py:98-99)
+            sd[c + ".weight"][:, c0:c0 + n] *= (1.0 / s)[None, :]
+    return sd
+
+
 def nerf_state_adversarial(seed):
     """White-noise density (no spectral decay, mostly empty space): the ill-conditioned stress scene."""
     return nerf_state(seed, sigma_shift=-40.0, pe_decay=0.0)

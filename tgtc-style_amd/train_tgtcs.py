@@ -143,6 +143,16 @@ def _init_distributed():
     return rank, world, local, dist
 
 
+def _broadcast_from_rank0(t, dist):
+    """In-place broadcast of a parameter table; gloo (several test ranks on one GPU) moves it through host memory."""
+    if dist.get_backend() == "nccl":
+        dist.broadcast(t, 0)
+    else:
+        host = t.detach().cpu()
+        dist.broadcast(host, 0)
+        t.copy_(host)
+
+
 def train(args):
     rank, world, local, dist = _init_distributed()
     if not torch.cuda.is_available():
@@ -212,7 +222,13 @@ def train(args):
         _, mu, logvar = vae.encode(feats)
         latents.style_latents_mu = torch.nn.Parameter(mu.detach())
         latents.style_latents_logvar = torch.nn.Parameter(logvar.detach())
-        latents.set_latents()
+        latents.set_latents(generator=torch.Generator().manual_seed(args.latent_seed) if args.latent_seed >= 0 else None)
+        if world > 1:
+            # the draw comes from each process's own unseeded generator: rank 0's table is THE table, or the stripes / frames
+            # of different ranks would be rendered with different style latents
+            latents = latents.to(device)
+            for p in (latents.latents, latents.style_latents_mu, latents.style_latents_logvar):
+                _broadcast_from_rank0(p.data, dist)
         print('Initializing Latent Model from', args.vae_pth_path)
     elif args.synthetic:
         latents.load_state_dict(_t(synth.latents_state(4, style_num=dataset.style_num, frame_num=dataset.frame_num)))

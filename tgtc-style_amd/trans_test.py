@@ -33,9 +33,17 @@ def _to_tensor(img):
 
 
 def _center_crop(img, h, w):
-    """torchvision.transforms.CenterCrop((h, w)) on a PIL image (trans_test.py:30-38): the crop window is centred with
-    int(round(.)) offsets; where it leaves the image PIL pads with black, as torchvision's pad-then-crop does."""
+    """torchvision.transforms.CenterCrop((h, w)) on a PIL image (trans_test.py:30-38): an image smaller than the crop is
+    first padded with black, left / top (crop - size) // 2 and right / bottom (crop - size + 1) // 2; the crop window of the
+    (padded) image then sits at int(round(.)) offsets."""
+    from PIL import Image
     W, H = img.size
+    if w > W or h > H:
+        pl, pt = ((w - W) // 2 if w > W else 0), ((h - H) // 2 if h > H else 0)
+        pr, pb = ((w - W + 1) // 2 if w > W else 0), ((h - H + 1) // 2 if h > H else 0)
+        padded = Image.new(img.mode, (W + pl + pr, H + pt + pb), 0)
+        padded.paste(img, (pl, pt))
+        img, (W, H) = padded, padded.size
     top, left = int(round((H - h) / 2.0)), int(round((W - w) / 2.0))
     return img.crop((left, top, left + w, top + h))
 
