@@ -182,9 +182,85 @@ def bench_style2d(precision, steps, warmup):
                          "note": "all kernels of the pass together (HIP events around the frame)"}}
 
 
+# one Origin_train iteration: MACs per network sample, forward / weight gradient (the same products) / input gradient (only
+# the activation columns of a layer carry a gradient: not the 63 encoding columns of L0 and L5, not the 27 of rgb_layers.0)
+MAC_TRAIN_DGRAD = MAC_FULL - 63 * 256 - 63 * 256 - 27 * 128
+FLOP_TRAIN_PER_SAMPLE = 2 * (2 * MAC_FULL + MAC_TRAIN_DGRAD)      # 3.489 MFLOP
+
+
+class _TorchNerf(torch.nn.Module):
+    """MLP_style / StyleNerf (reference models.py:63-117, :182-223) as stock torch modules: the comparator of `train_step`."""
+
+    def __init__(self, sd):
+        super().__init__()
+        lin = lambda name: self._linear(sd["net." + name + ".weight"], sd["net." + name + ".bias"])
+        self.base = torch.nn.ModuleList([lin("base_layers.%d" % i) for i in range(8)])
+        self.sigma, self.remap = lin("sigma_layer"), lin("base_remap_layer")
+        self.rgb = torch.nn.ModuleList([lin("rgb_layers.0"), lin("rgb_layers.1")])
+
+    @staticmethod
+    def _linear(w, b):
+        m = torch.nn.Linear(w.shape[1], w.shape[0])
+        m.weight.data.copy_(torch.from_numpy(w)), m.bias.data.copy_(torch.from_numpy(b))
+        return m
+
+    @staticmethod
+    def embed(x, L):
+        out = [x]
+        for k in range(L):
+            out += [torch.sin(x * 2.0 ** k), torch.cos(x * 2.0 ** k)]
+        return torch.cat(out, -1).to(torch.float32)
+
+    def forward(self, pts, dirs):
+        pe, de = self.embed(pts, 10), self.embed(dirs, 4)
+        h = torch.relu(self.base[0](pe))
+        for i in range(7):
+            if i == 4:
+                h = torch.cat([pe, h], -1)
+            h = torch.relu(self.base[i + 1](h))
+        sigma = self.sigma(h).squeeze(-1)
+        f = torch.relu(self.rgb[0](torch.cat([torch.relu(self.remap(h)), de], -1)))
+        return torch.sigmoid(self.rgb[1](f)), sigma
+
+
+def _torch_origin_train_step(m, mf, opt, ro, rd, gt, nc, nf, noise_std):
+    """train_tgtcs.py:226-254 in stock torch-ROCm eager autograd (fp32 rocBLAS GEMMs): the comparator, not a target."""
+    R = ro.shape[0]
+    ts = torch.linspace(0., 1., nc, device=ro.device).expand(R, nc)
+    mid = .5 * (ts[..., 1:] + ts[..., :-1])
+    ts = torch.cat([ts[..., :1], mid], -1) + (torch.cat([mid, ts[..., -1:]], -1) - torch.cat([ts[..., :1], mid], -1)) * torch.rand_like(ts)
+
+    def composite(rgb, sigma, t):
+        delta = torch.cat([t[..., 1:] - t[..., :-1], torch.full_like(t[..., :1], 1e10)], -1)
+        alpha = 1. - torch.exp(-torch.relu(torch.relu(sigma + torch.randn_like(sigma) * noise_std)) * delta)
+        trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1. - alpha + 1e-10], -1), -1)[:, :-1]
+        w = alpha * trans
+        return (w[..., None] * rgb).sum(-2), w
+
+    rgb, sigma = m(ro[:, None, :] + ts[..., None].double() * rd[:, None, :], rd[:, None, :].expand(R, nc, 3))
+    rgb_c, w = composite(rgb, sigma, ts)
+    with torch.no_grad():                                   # sample_pdf on detached weights (utils.py:573-609)
+        pdf = w[:, 1:-1] + 1e-5
+        pdf = pdf / pdf.sum(-1, keepdim=True)
+        cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+        u = torch.linspace(0., 1., nf, device=ro.device).expand(R, nf).contiguous()
+        idx = torch.searchsorted(cdf, u, right=True)
+        lo, hi = (idx - 1).clamp(min=0), idx.clamp(max=cdf.shape[-1] - 1)
+        c0, c1, b0, b1 = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi), torch.gather(mid, -1, lo), torch.gather(mid, -1, hi)
+        den = torch.where(c1 - c0 < 1e-5, torch.ones_like(c0), c1 - c0)
+        tf = torch.sort(torch.cat([ts, b0 + (u - c0) / den * (b1 - b0)], -1), -1)[0]
+    rgb, sigma = mf(ro[:, None, :] + tf[..., None].double() * rd[:, None, :], rd[:, None, :].expand(R, nc + nf, 3))
+    rgb_f, _ = composite(rgb, sigma, tf)
+    loss = torch.mean((rgb_c - gt) ** 2) + torch.mean((rgb_f - gt) ** 2)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return loss
+
+
 def bench_train_step(steps, warmup, rays=1024):
     """one iteration of the reference's Origin_train body (coarse + fine losses, sigma noise, Adam) on
-    the differentiable, unfused HIP dense layers.  ms per iteration."""
+    the differentiable HIP dense layers, with the same iteration in stock torch eager autograd beside it.  ms per iteration."""
     from tgtc_style_amd import models, synth, training
     rng = np.random.default_rng(1)
     ro = torch.from_numpy(rng.uniform(-0.3, 0.3, (rays, 3))).cuda()
@@ -194,18 +270,36 @@ def bench_train_step(steps, warmup, rays=1024):
     m.load_state_dict(t_state(synth.nerf_state(0))), mf.load_state_dict(t_state(synth.nerf_state(1)))
     m, mf = m.cuda().trainable(), mf.cuda().trainable()
     opt = torch.optim.Adam(list(m.parameters()) + list(mf.parameters()), lr=5e-4)
-    for i in range(warmup + steps):
-        if i == warmup:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        r = training.origin_train_step(m, mf, opt, ro, rd, gt, 64, 64, 0., 1., sigma_noise_std=0.1)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    samples = rays * (64 + 128)
+
+    def timed(fn):
+        for i in range(warmup + steps):
+            if i == warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3, r
+
+    ms, r = timed(lambda: training.origin_train_step(m, mf, opt, ro, rd, gt, 64, 64, 0., 1., sigma_noise_std=0.1))
     assert np.isfinite(r["loss"])
+    tm, tmf = _TorchNerf(synth.nerf_state(0)).cuda(), _TorchNerf(synth.nerf_state(1)).cuda()
+    topt = torch.optim.Adam(list(tm.parameters()) + list(tmf.parameters()), lr=5e-4)
+    ms_torch, loss_t = timed(lambda: _torch_origin_train_step(tm, tmf, topt, ro, rd, gt, 64, 64, 0.1))
+    assert bool(torch.isfinite(loss_t))
+    samples = rays * (64 + 128)
+    flop = float(FLOP_TRAIN_PER_SAMPLE) * samples
+    achieved = flop / (ms * 1e-3) / 1e12
     return {"metric": "ms per Origin_train iteration (1024 rays, 64 coarse + 128 fine-pass network samples, forward + backward + Adam) "
-                      "on the unfused differentiable HIP dense layers", "value": ms, "unit": "ms", "higher_is_better": False,
-            "steps": steps, "dtype": "fp16x3", "network_samples_per_s": samples / (ms * 1e-3)}
+                      "on the differentiable HIP dense layers", "value": ms, "unit": "ms", "higher_is_better": False,
+            "steps": steps, "dtype": "fp16x3", "network_samples_per_s": samples / (ms * 1e-3),
+            "flop_per_iter": flop,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP16_TFLOPS,
+                         "note": "algorithmic flops of forward + input gradients + weight gradients (%.3f MFLOP per network sample) / wall "
+                                 "time of the whole iteration, sampling, compositing and Adam included; fp16x3 issues 3 MFMA products per "
+                                 "algorithmic product" % (FLOP_TRAIN_PER_SAMPLE / 1e6)},
+            "comparator": {"what": "the same Origin_train iteration in stock torch-ROCm eager autograd (fp32 rocBLAS GEMMs, torch "
+                                   "elementwise / cumprod / searchsorted kernels) on the same GPU, same rays; a baseline, not a target",
+                           "value": ms_torch, "unit": "ms", "speedup": ms_torch / ms}}
 
 
 def make_renderer(precision, styled):

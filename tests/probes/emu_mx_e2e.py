@@ -24,6 +24,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from oracle import fields, raymarch  # noqa: E402
 from tgtc_style_amd import synth  # noqa: E402
 
+ACT_SHIFT = int(os.environ.get("EMU_ACT_SHIFT", "1"))    # activation block scale 2^(E - ACT_SHIFT): 1 = codes in [2,4) (the kernel's), 2 = [4,8)
+AL_SHIFT = int(os.environ.get("EMU_AL_SHIFT", "0"))      # lo-activation block scale 2^(E - ACT_SHIFT - 11 - AL_SHIFT): 0 = the round-2 kernel
+W_SHIFT = os.environ.get("EMU_W_SHIFT", "1")               # weight row scale: "1", "2", or "best" (per row, least squared error)
 E2M3 = np.array([(c & 7) * 0.125 if (c >> 3) == 0 else (1 + (c & 7) / 8) * 2.0 ** ((c >> 3) - 1) for c in range(32)])
 
 
@@ -59,10 +62,11 @@ def split_act(a, fmt):
     for idx in act_blocks(a.shape[1]):
         m = ah[:, idx].max(1)
         e = np.floor(np.log2(np.maximum(m, 2.0 ** -14)))
-        s = (2.0 ** (e - 1))[:, None]
+        s = (2.0 ** (e - ACT_SHIFT))[:, None]
         if fmt == "e2m3":
             ah6[:, idx] = e2m3(ah[:, idx] / s) * s
-            al6[:, idx] = e2m3(al[:, idx] / (s / 2048)) * (s / 2048)
+            sl = s / 2048 / 2.0 ** AL_SHIFT
+            al6[:, idx] = e2m3(al[:, idx] / sl) * sl
         else:   # MX-fp8: block scale puts the block maximum at 2^7 (e4m3 max 448)
             s8 = s / 64
             ah6[:, idx] = e4m3(ah[:, idx] / s8) * s8
@@ -76,6 +80,18 @@ def split_w(W, fmt):
     m = np.abs(wh).max(1)
     e = np.floor(np.log2(np.maximum(m, 2.0 ** -14)))
     sh = (2.0 ** (e - 1))[:, None]
+    if fmt == "e2m3" and W_SHIFT != "1":
+        def q(x, s0):
+            cands = [s0, s0 / 2] if W_SHIFT == "best" else [s0 / 2]
+            out, err = None, None
+            for sc in cands:
+                v = e2m3(x / sc) * sc
+                er = ((v - x) ** 2).sum(1, keepdims=True)
+                out = v if out is None else np.where(er < err, v, out)
+                err = er if err is None else np.minimum(er, err)
+            return out
+        el = np.floor(np.log2(np.maximum(np.abs(wl).max(1), 2.0 ** -40)))
+        return wh, wl, q(wh, sh), q(wl, (2.0 ** (el - 1))[:, None])
     if fmt == "e2m3":
         return wh, wl, e2m3(wh / sh) * sh, e2m3(wl / (sh / 2048)) * (sh / 2048)
     s8 = sh / 64

@@ -251,3 +251,78 @@ def test_style_train_step_reduces_the_loss():
     after = (cm.layers[0].weight, sm.layers[7].weight, lat.latents)
     assert all(float((a.detach() - b).abs().max()) > 0 for a, b in zip(after, before))
     assert torch.equal(model.net.base_layers[0].weight.detach(), nerf_before) and model.net.base_layers[0].weight.grad is None
+
+
+def test_style_train_coherence_term_matches_the_oracle():
+    """The second, frame-ordered batch of a Style_train iteration and its cosine-coherence term (train_tgtcs.py:366-403,
+    :436-458; VGGNet.py:204-210; utils.py:459): two consecutive iterations through training.style_train_step.  The
+    coherence loss of the second one and its gradient w.r.t. the latent table -- which reaches the loss through the latent
+    gather, both style MLPs and compositing of the coarse AND the fine pass -- against float64 autograd on the oracle's
+    formulas (carried colours detached, as CoherenceState documents)."""
+    from tgtc_style_amd import models, training
+    rng = np.random.default_rng(7)
+    R, NC, NF = 48, 64, 64
+    sds = [synth.nerf_state(0), synth.nerf_state(1), synth.concat_state(2), synth.style_state(3)]
+    lsd = synth.latents_state(4, style_num=1, frame_num=20)
+
+    def batch(seed):
+        g = np.random.default_rng(seed)
+        return {"rays_o": torch.from_numpy(g.uniform(-0.3, 0.3, (R, 3))), "rays_d": torch.from_numpy(g.uniform(-1, 1, (R, 3)) * [0.4, 0.4, 0.1] + [0, 0, -1.0]),
+                "rgb_origin": torch.from_numpy(g.uniform(0.1, 0.9, (R, 3)).astype(np.float32)), "style_id": torch.zeros(R, dtype=torch.long),
+                "frame_id": torch.full((R,), seed % 20, dtype=torch.long), "jitter": torch.from_numpy(g.uniform(0, 1, (R, NC)).astype(np.float32))}
+    b1, b2, main = batch(11), batch(12), batch(13)
+    gt = torch.from_numpy(rng.uniform(0.2, 0.8, (R, 3)).astype(np.float32))
+
+    model, model_fine = models.StyleNerf(Args, mode="coarse"), models.StyleNerf(Args, mode="fine")
+    model.load_state_dict(T(sds[0])), model_fine.load_state_dict(T(sds[1]))
+    model, model_fine = model.cuda(), model_fine.cuda()
+    model.set_enable_style(True), model_fine.set_enable_style(True)
+    cm, sm = models.StyleMLP_before_concat(Args), models.StyleMLP_Wild_multilayers(Args)
+    cm.load_state_dict(T(sds[2])), sm.load_state_dict(T(sds[3]))
+    lat = models.StyleLatents_variational(style_num=1, frame_num=20, latent_dim=32)
+    lat.load_state_dict(T(lsd))
+    cm, sm, lat = cm.cuda().trainable(), sm.cuda().trainable(), lat.cuda().trainable()
+    lat.sigma_scale = 1.0
+    opt = torch.optim.SGD(list(cm.parameters()) + list(sm.parameters()) + [lat.latents], lr=0.0)    # lr 0: weights stay the oracle's
+    cuda = lambda b: {k: v.cuda() for k, v in b.items()}
+    state = training.CoherenceState(frame_num=20)
+    kw = dict(sigma_noise_std=0.0, rgb_loss_lambda=0.0, logp_loss_lambda=0.0, coherence=state, loss_coh_lambda=1.0)
+    args = (model, model_fine, cm, sm, lat, opt, main["rays_o"].cuda(), main["rays_d"].cuda(), gt.cuda(), main["style_id"].cuda(),
+            main["frame_id"].cuda(), NC, NF, 0., 1.)
+    r1 = training.style_train_step(*args, jitter=main["jitter"].cuda(), coh_batch=cuda(b1), **kw)
+    assert r1["loss_coh"] == 0.0 and state.cnt == 1                      # first batch: nothing to compare with (:400)
+    r2 = training.style_train_step(*args, jitter=main["jitter"].cuda(), coh_batch=cuda(b2), **kw)
+    got_grad = lat.latents.grad.detach().cpu().double()                  # rgb / logp weights are 0: this is d loss_coh / d latents
+    assert state.cnt == 2 and r2["loss_coh"] > 0
+
+    def oracle(dtype):
+        w = [T(sd, dtype) for sd in sds]
+        lw = {k: v.clone().to(dtype).requires_grad_() for k, v in T(lsd).items()}
+
+        def styled(b):
+            ro, rd = b["rays_o"], b["rays_d"]
+            z = fields.latents_forward(lw, b["style_id"], b["frame_id"], sigma_scale=1.0, llff=True)
+            pts, ts = raymarch.sample_coarse(ro, rd, NC, 0., 1., b["jitter"])
+            rgb, sig = fields._styled_pass(w[0], w[2], w[3], pts, rd[:, None, :].expand(-1, NC, -1), z)
+            rgb_c, _, wc = raymarch.composite(rgb, sig, ts)
+            pts_f, ts_f = raymarch.sample_fine(ro, rd, ts, wc.detach(), NF)
+            rgb, sig = fields._styled_pass(w[1], w[2], w[3], pts_f, rd[:, None, :].expand(-1, NC + NF, -1), z)
+            rgb_f, _, _ = raymarch.composite(rgb, sig, ts_f)
+            return rgb_c, rgb_f
+        cos = lambda a, b: ((a / (a.norm(dim=1, keepdim=True) + 1e-8)) * (b / (b.norm(dim=1, keepdim=True) + 1e-8))).sum(1)
+        l2 = lambda x: torch.sqrt((x ** 2).sum() + 1e-8)
+        with torch.no_grad():
+            x, y = styled(b1)
+        c, f = styled(b2)
+        o1, o2 = b1["rgb_origin"].to(dtype), b2["rgb_origin"].to(dtype)
+        loss = l2(cos(c, x) - cos(o2, o1)) + l2(cos(f, y) - cos(o2, o2))      # :401, :456 (x_origin is already o2 there)
+        loss.backward()
+        return float(loss), lw["latents"].grad.double()
+    loss64, grad64 = oracle(torch.float64)
+    loss32, grad32 = oracle(torch.float32)
+    print("loss_coh %.6f (oracle f64 %.6f, f32 %.6f)" % (r2["loss_coh"], loss64, loss32))
+    assert abs(r2["loss_coh"] - loss64) <= 1e-3 * max(1.0, abs(loss64))
+    scale = float(grad64.abs().max())
+    err, yard = float((got_grad - grad64).abs().max()) / scale, float((grad32 - grad64).abs().max()) / scale
+    print("d loss_coh / d latents: rel err %.2e (float32 oracle: %.2e)" % (err, yard))
+    assert scale > 0 and err <= max(2e-3, 5 * yard)
