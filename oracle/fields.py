@@ -55,10 +55,12 @@ def nerf_mlp(sd, pts_enc, dirs_enc, depth=8, skips=(4,), use_viewdir=True, prefi
     return {"rgb": rgb, "base_remap": remap, "pts": pts_enc, "sigma": sigma}
 
 
-def style_nerf(sd, pts, dirs, freq_coor=10, freq_dir=4, **kw):
-    """StyleNerf.forward: encode (in the input dtype), cast to float32, run the MLP.  models.py:216-223."""
-    pe = posenc(pts, freq_coor).to(torch.float32)
-    de = posenc(dirs, freq_dir).to(torch.float32)
+def style_nerf(sd, pts, dirs, freq_coor=10, freq_dir=4, dtype=torch.float32, **kw):
+    """StyleNerf.forward: encode (in the input dtype), cast to float32, run the MLP.  models.py:216-223.
+    dtype=float64 (with float64 weights in sd) evaluates the same formulas in double precision: the conditioning probe
+    of the whole-frame tests, not the reference's arithmetic."""
+    pe = posenc(pts, freq_coor).to(dtype)
+    de = posenc(dirs, freq_dir).to(dtype)
     out = nerf_mlp(sd, pe, de, **kw)
     out["dirs"] = de
     return out
@@ -122,31 +124,34 @@ def vae_encode(sd, x, depth=4):
     return _lin(sd, "encoder.fc_layer_mu", h), _lin(sd, "encoder.fc_layer_log_var", h)
 
 
-def render_plain(sd_coarse, sd_fine, rays_o, rays_d, n_coarse, n_fine, near=0., far=1.):
+def render_plain(sd_coarse, sd_fine, rays_o, rays_d, n_coarse, n_fine, near=0., far=1., dtype=torch.float32, dtype_fine=None):
     """The cal_geometry chain, one chunk.  rendering.py:27-51 (perturb=False, det fine sampling).
 
     Returns dict with coarse and fine rgb_exp / t_exp / weights plus the fine t values.
+    dtype / dtype_fine = float64 (with float64 state dicts): the coarse / fine half of the chain in double precision -- the
+    conditioning probes of the whole-frame tests (tests/conditioning.py), not the reference's arithmetic.
     """
-    pts, ts = raymarch.sample_coarse(rays_o, rays_d, n_coarse, near, far)
+    dtype_fine = dtype_fine or dtype
+    pts, ts = raymarch.sample_coarse(rays_o, rays_d, n_coarse, near, far, dtype=dtype)
     dirs = rays_d[:, None, :].expand(-1, n_coarse, -1)
-    c = style_nerf(sd_coarse, pts, dirs)
+    c = style_nerf(sd_coarse, pts, dirs, dtype=dtype)
     rgb_c, t_c, w_c = raymarch.composite(c["rgb"], c["sigma"], ts)
-    pts_f, ts_f = raymarch.sample_fine(rays_o, rays_d, ts, w_c, n_fine)
+    pts_f, ts_f = raymarch.sample_fine(rays_o, rays_d, ts.to(dtype_fine), w_c.to(dtype_fine), n_fine)
     dirs = rays_d[:, None, :].expand(-1, n_coarse + n_fine, -1)
-    f = style_nerf(sd_fine, pts_f, dirs)
+    f = style_nerf(sd_fine, pts_f, dirs, dtype=dtype_fine)
     rgb_f, t_f, w_f = raymarch.composite(f["rgb"], f["sigma"], ts_f)
     return {"rgb_coarse": rgb_c, "t_coarse": t_c, "w_coarse": w_c, "ts_fine": ts_f,
             "sigma_fine": f["sigma"], "rgb_fine": rgb_f, "t_fine": t_f, "w_fine": w_f}
 
 
-def _styled_pass(sd_nerf, sd_concat, sd_style, pts, dirs, z):
+def _styled_pass(sd_nerf, sd_concat, sd_style, pts, dirs, z, dtype=torch.float32):
     """One pass of the stylised chain.  rendering.py:122-142 (= :158-175 for the fine pass).
 
     z [R,32] is the per-ray latent; the concat MLP receives it as is, the style MLP receives its
     mean over the 32 channels broadcast back to 32 (rendering.py:126,139).
     """
     n = pts.shape[1]
-    out = style_nerf(sd_nerf, pts, dirs)
+    out = style_nerf(sd_nerf, pts, dirs, dtype=dtype)
     z1 = z[:, None, :].expand(-1, n, -1)
     cf = concat_mlp(sd_concat, out["pts"], z1)["concat_features"]
     both = torch.cat([out["base_remap"], cf], -1)
@@ -156,15 +161,15 @@ def _styled_pass(sd_nerf, sd_concat, sd_style, pts, dirs, z):
 
 
 def render_styled(sd_coarse, sd_fine, sd_concat, sd_style, rays_o, rays_d, z,
-                  n_coarse, n_fine, near=0., far=1., jitter=None):
-    """The render_style chain, one batch.  rendering.py:118-178."""
-    pts, ts = raymarch.sample_coarse(rays_o, rays_d, n_coarse, near, far, jitter)
+                  n_coarse, n_fine, near=0., far=1., jitter=None, dtype=torch.float32):
+    """The render_style chain, one batch.  rendering.py:118-178.  dtype=float64: see render_plain."""
+    pts, ts = raymarch.sample_coarse(rays_o, rays_d, n_coarse, near, far, jitter, dtype=dtype)
     dirs = rays_d[:, None, :].expand(-1, n_coarse, -1)
-    rgb, sig = _styled_pass(sd_coarse, sd_concat, sd_style, pts, dirs, z)
+    rgb, sig = _styled_pass(sd_coarse, sd_concat, sd_style, pts, dirs, z, dtype)
     rgb_c, t_c, w_c = raymarch.composite(rgb, sig, ts)
     pts_f, ts_f = raymarch.sample_fine(rays_o, rays_d, ts, w_c, n_fine)
     dirs = rays_d[:, None, :].expand(-1, n_coarse + n_fine, -1)
-    rgb, sig = _styled_pass(sd_fine, sd_concat, sd_style, pts_f, dirs, z)
+    rgb, sig = _styled_pass(sd_fine, sd_concat, sd_style, pts_f, dirs, z, dtype)
     rgb_f, t_f, w_f = raymarch.composite(rgb, sig, ts_f)
     return {"rgb_coarse": rgb_c, "t_coarse": t_c, "w_coarse": w_c, "ts_fine": ts_f,
             "rgb_fine": rgb_f, "t_fine": t_f, "w_fine": w_f}

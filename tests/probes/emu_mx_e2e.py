@@ -104,6 +104,15 @@ def make_linear(mode):
         return lambda a, W, b: a.astype(np.float64) @ W.astype(np.float64).T + b
     if mode == "fp16":
         return lambda a, W, b: a.astype(np.float16).astype(np.float64) @ W.astype(np.float16).astype(np.float64).T + b
+    if mode == "fp16x3":      # hi*hi + lo*hi + hi*lo with fp16 operands (lo may be an fp16 subnormal, or flush below 6e-8)
+        def x3(a, W, b):
+            ah = a.astype(np.float16)
+            al = (a.astype(np.float32) - ah.astype(np.float32)).astype(np.float16).astype(np.float64)
+            wh = W.astype(np.float16)
+            wl = (W.astype(np.float32) - wh.astype(np.float32)).astype(np.float16).astype(np.float64)
+            ah, wh = ah.astype(np.float64), wh.astype(np.float64)
+            return ah @ wh.T + al @ wh.T + ah @ wl.T + b
+        return x3
     fmt = "e4m3" if "fp8" in mode else "e2m3"
 
     def lin(a, W, b):

@@ -302,11 +302,11 @@ def test_style_train_coherence_term_matches_the_oracle():
         def styled(b):
             ro, rd = b["rays_o"], b["rays_d"]
             z = fields.latents_forward(lw, b["style_id"], b["frame_id"], sigma_scale=1.0, llff=True)
-            pts, ts = raymarch.sample_coarse(ro, rd, NC, 0., 1., b["jitter"])
-            rgb, sig = fields._styled_pass(w[0], w[2], w[3], pts, rd[:, None, :].expand(-1, NC, -1), z)
+            pts, ts = raymarch.sample_coarse(ro, rd, NC, 0., 1., b["jitter"].to(dtype), dtype=dtype)
+            rgb, sig = fields._styled_pass(w[0], w[2], w[3], pts, rd[:, None, :].expand(-1, NC, -1), z, dtype)
             rgb_c, _, wc = raymarch.composite(rgb, sig, ts)
             pts_f, ts_f = raymarch.sample_fine(ro, rd, ts, wc.detach(), NF)
-            rgb, sig = fields._styled_pass(w[1], w[2], w[3], pts_f, rd[:, None, :].expand(-1, NC + NF, -1), z)
+            rgb, sig = fields._styled_pass(w[1], w[2], w[3], pts_f, rd[:, None, :].expand(-1, NC + NF, -1), z, dtype)
             rgb_f, _, _ = raymarch.composite(rgb, sig, ts_f)
             return rgb_c, rgb_f
         cos = lambda a, b: ((a / (a.norm(dim=1, keepdim=True) + 1e-8)) * (b / (b.norm(dim=1, keepdim=True) + 1e-8))).sum(1)

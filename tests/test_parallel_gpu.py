@@ -65,7 +65,7 @@ def test_two_ranks_equal_one(tmp_path, n_pixels, H, W):
     assert rows == n_pixels and finite == 1 and same == 1
 
 
-def _nccl_worker(port, out_path):
+def _nccl_worker(_rank, port, out_path):
     """One rank, backend nccl (= RCCL on ROCm); the process group comes up before the first HIP call of the process."""
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -321,6 +321,14 @@ extern "C" int tgtc_nerf_create(const tgtc_linear* layers, int n_layers, int pre
     }
     std::vector<char> bias_region, stream;
     int n_frags = 0;
+    // per-feature scales of the ReLU trunk balanced by powers of two first (mlp_pack.h, EqualisedNet): the same function,
+    // numbers that every precision mode represents well.  base_remap's rows stay: it is an output of the operator.
+    EqualisedNet eq;
+    eq.copy(layers, 12);
+    for (int l = 0; l < 7; ++l) eq.run(l, {{l + 1, l + 1 == 5 ? 63 : 0}});   // layer 5 reads cat(pe(63), h) (models.py:98-99)
+    eq.run(7, {{8, 0}, {9, 0}});                                              // sigma_layer and base_remap_layer read h
+    eq.run(10, {{11, 0}});                                                    // rgb_layers.0 -> rgb_layers.1
+    layers = eq.lin.data();
     if (precision == TGTC_PREC_FP16_FP6) {
         const int rc = nerf_mx_pack(layers, bias_region, stream);
         if (rc != TGTC_OK) return rc;

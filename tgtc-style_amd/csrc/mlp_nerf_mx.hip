@@ -93,61 +93,7 @@ static int e2m3_encode(float x) {
     return c | (std::signbit(x) ? 32 : 0);
 }
 
-// Power-of-two cross-layer equalisation of the ReLU layers before packing.  The block-scaled corrections lose their
-// benefit with the dynamic range inside a 32-value block (activations) or a weight row (one exponent per row): a feature
-// whose activations run 64 x above its neighbours' flushes their fp6 codes, a consumer column 64 x below its row's maximum
-// loses its own.  A ReLU layer is positively homogeneous, so row i of layer l (and its bias) times 2^-k and column i of
-// every consumer of that feature times 2^k is the SAME function -- exactly, powers of two commute with every rounding --
-// and k_i = round(log2(rowmax_i / colmax_i) / 2) balances the two ranges feature by feature (what cross-layer range
-// equalisation does for integer quantisation).  Trained networks carry exactly this kind of per-feature scale freedom;
-// tests/probes/emu_mx_e2e.py measures what it is worth (profiles/r3_precision_emulation.md).  The remap layer's rows
-// stay as they are: base_remap is an output of the operator.
-struct EqualisedNerf {
-    std::vector<float> w[12], b[12];
-    tgtc_linear lin[12];
-};
-static void nerf_mx_equalise(const tgtc_linear* layers, EqualisedNerf& e) {
-    for (int l = 0; l < 12; ++l) {
-        e.w[l].assign(layers[l].weight, layers[l].weight + (size_t)layers[l].out_features * layers[l].in_features);
-        e.b[l].assign(layers[l].bias, layers[l].bias + layers[l].out_features);
-    }
-    struct Cons { int layer, col0; };
-    auto run = [&](int l, std::initializer_list<Cons> cons) {
-        const int n = layers[l].out_features, in = layers[l].in_features;
-        std::vector<int> k(n, 0);
-        for (int i = 0; i < n; ++i) {
-            float r1 = 0.0f, r2 = 0.0f;
-            for (int c = 0; c < in; ++c) r1 = std::fmax(r1, std::fabs(e.w[l][(size_t)i * in + c]));
-            for (const Cons& q : cons)
-                for (int r = 0; r < layers[q.layer].out_features; ++r)
-                    r2 = std::fmax(r2, std::fabs(e.w[q.layer][(size_t)r * layers[q.layer].in_features + q.col0 + i]));
-            if (r1 > 0.0f && r2 > 0.0f) k[i] = (int)std::nearbyint(0.5 * std::log2((double)r1 / (double)r2));
-        }
-        std::vector<int> sorted(k);
-        std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
-        const int med = sorted[n / 2];   // only the spread matters: keep the layer's typical activation scale
-        for (int i = 0; i < n; ++i) {
-            const int ki = std::max(-8, std::min(8, k[i] - med));
-            if (ki == 0) continue;
-            const float down = std::ldexp(1.0f, -ki), up = std::ldexp(1.0f, ki);
-            for (int c = 0; c < in; ++c) e.w[l][(size_t)i * in + c] *= down;
-            e.b[l][i] *= down;
-            for (const Cons& q : cons)
-                for (int r = 0; r < layers[q.layer].out_features; ++r)
-                    e.w[q.layer][(size_t)r * layers[q.layer].in_features + q.col0 + i] *= up;
-        }
-    };
-    for (int l = 0; l < 7; ++l) run(l, {{l + 1, l + 1 == 5 ? 63 : 0}});   // layer 5 reads cat(pe(63), h) (models.py:98-99)
-    run(7, {{8, 0}, {9, 0}});                                              // sigma_layer and base_remap_layer read h
-    run(10, {{11, 0}});                                                    // rgb_layers.0 -> rgb_layers.1
-    for (int l = 0; l < 12; ++l) e.lin[l] = tgtc_linear{e.w[l].data(), e.b[l].data(), layers[l].out_features, layers[l].in_features};
-}
-
-int nerf_mx_pack(const tgtc_linear* layers_in, std::vector<char>& bias_region, std::vector<char>& stream) {
-    EqualisedNerf eq;
-    const char* no_eq = std::getenv("TGTC_MX_NO_EQUALISE");   // development: pack the weights as given
-    if (!(no_eq && no_eq[0] == '1')) nerf_mx_equalise(layers_in, eq);
-    const tgtc_linear* layers = (no_eq && no_eq[0] == '1') ? layers_in : eq.lin;
+int nerf_mx_pack(const tgtc_linear* layers, std::vector<char>& bias_region, std::vector<char>& stream) {
     const std::vector<LayerSpec> specs = nerf_specs(layers);
     const MxTable& T = kNerfMxTable;
     bias_region.assign(kNerfBiasBytes, 0);
@@ -171,30 +117,55 @@ int nerf_mx_pack(const tgtc_linear* layers_in, std::vector<char>& bias_region, s
             return (row < Ls.out && col >= 0 && col < Ls.in) ? Ls.W[(size_t)row * Ls.in + col] : 0.0f;
         };
         for (int rt = 0; rt < sh.rt; ++rt) {
-            int E[16];  // exponent of the largest |fp16(w)| of each row over the activation columns
+            // Block exponents of the two fp6 weight operands of each row, one per row over all activation columns and chosen
+            // independently for Wh6 (the fp16 weights) and Wl6 (their rounding residuals): the exponent of the operand's own
+            // largest magnitude puts the codes in [2,4) (no saturation), one below in [4,8) (finer steps, the few values above
+            // 7.5 saturate); the packer takes whichever leaves the smaller squared error.  (Round 2 tied Wl6 to Wh6's exponent
+            // minus 11, which left the residuals two binades below the top of the code range: tests/probes/emu_mx_e2e.py,
+            // EMU_W_SHIFT=best, median end-to-end error 2.3e-5 -> 7.7e-6.)
+            int EH[16], EL[16];
             for (int r = 0; r < 16; ++r) {
                 const int row = 16 * rt + r;
                 bias[b0 + 16 * rt + r] = row < Ls.out ? Ls.b[row] : 0.0f;
-                float mx = 0.0f;
-                if (act)
-                    for (int c = 0; c < 128 * sh.nkb; ++c) mx = std::fmax(mx, std::fabs((float)(half_t)weight(row, act->col0 + c)));
-                int e = -14;
-                if (mx > 0.0f) {
-                    (void)std::frexp(mx, &e);  // mx = f * 2^e, f in [0.5, 1)
+                auto best = [&](bool lo) {
+                    float mx = 0.0f;
+                    const int ncol = act ? 128 * sh.nkb : 0;
+                    for (int c = 0; c < ncol; ++c) {
+                        const float w = weight(row, act->col0 + c);
+                        const float hi = (float)(half_t)w;
+                        mx = std::fmax(mx, std::fabs(lo ? w - hi : hi));
+                    }
+                    if (!(mx > 0.0f)) return -14 - (lo ? 11 : 0);
+                    int e = 0;
+                    (void)std::frexp(mx, &e);   // mx = f * 2^e, f in [0.5, 1): the value's exponent is e - 1
                     e -= 1;
-                    if (e < -14) e = -14;
-                }
-                E[r] = e;
-                const int byte_h = e - 1 + 127;
-                rowexp[b0 + 16 * rt + r] = (unsigned short)(byte_h | ((byte_h - 11) << 8));
+                    int pick = e - 1;
+                    double err_best = -1.0;
+                    for (int cand = e - 1; cand >= e - 2; --cand) {
+                        if (cand < -126) continue;
+                        const float inv = std::ldexp(1.0f, -cand), sc = std::ldexp(1.0f, cand);
+                        double err = 0.0;
+                        for (int c = 0; c < ncol; ++c) {
+                            const float w = weight(row, act->col0 + c);
+                            const float hi = (float)(half_t)w;
+                            const float v = lo ? w - hi : hi;
+                            const double d = (double)e2m3_value(e2m3_encode(v * inv)) * sc - (double)v;
+                            err += d * d;
+                        }
+                        if (err_best < 0.0 || err < err_best) err_best = err, pick = cand;
+                    }
+                    return pick;
+                };
+                EH[r] = best(false), EL[r] = best(true);
+                rowexp[b0 + 16 * rt + r] = (unsigned short)((EH[r] + 127) | ((EL[r] + 127) << 8));
             }
             for (int kb = 0; kb < sh.nkb; ++kb, ++qi) {
                 char* base = stream.data() + T.off[qi];
                 for (int lane = 0; lane < 64; ++lane) {
                     const int m = lane & 15, g = lane >> 4, row = 16 * rt + m;
                     unsigned long long bl[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
-                    const float inv_l = std::ldexp(1.0f, -(E[m] - 12));  // Wl6 scale 2^(E-1-11)
-                    const float inv_h = std::ldexp(1.0f, -(E[m] - 1));   // Wh6 scale 2^(E-1)
+                    const float inv_l = std::ldexp(1.0f, -EL[m]);  // Wl6 = e2m3(wl / 2^EL)
+                    const float inv_h = std::ldexp(1.0f, -EH[m]);  // Wh6 = e2m3(wh / 2^EH)
                     auto put = [](unsigned long long (&b)[3], int i, int code) {
                         const int bit = 6 * i;
                         b[bit / 64] |= (unsigned long long)code << (bit % 64);

@@ -2,10 +2,14 @@
 // fragment-ordered fp16 (hi [+ lo]) stream the fused kernels consume through the LDS ring,
 // plus a padded fp32 bias table.  The k-slot -> input-column maps live in mlp_core.h.
 #pragma once
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <vector>
 
+#include "../../include/tgtc_hip.h"
 #include "common.h"
 #include "mlp_core.h"
 
@@ -42,6 +46,68 @@ inline int seg_col(const Seg& s, int ks_in_seg, int g, int j) {
     }
     return c < 0 ? -1 : s.col0 + c;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Power-of-two cross-layer equalisation of ReLU layers before packing (every precision).
+//
+// fp16 operands have a 30-binade exponent range and the parity modes lean on its lower end: the lo halves of fp16x3 are
+// 2^-11 of their values (an activation of 1e-3 has a lo of 5e-7, an fp16 subnormal with three significant bits; below
+// 6e-8 it is gone), and the block-scaled corrections of fp16mx lose their benefit with the dynamic range inside a
+// 32-value block (activations) or a weight row.  A network whose features live on very different scales -- what trained
+// MLPs look like -- therefore loses accuracy in EVERY mode (tests/probes/emu_mx_e2e.py: log-normal per-feature scales
+// put 6e-3 on a rendered ray in fp16x3, 4e-3 in fp16mx; equalised: 2e-6 / 2e-4).  A ReLU layer is positively
+// homogeneous, so row i of layer l (and its bias) times 2^-k and column i of every consumer of that feature times 2^k is
+// the SAME function -- exactly: powers of two commute with every rounding short of overflow -- and
+// k_i = round(log2(rowmax_i / colmax_i) / 2), taken relative to the layer's median, balances the row's range against
+// its consumers' column range feature by feature (cross-layer range equalisation, as used for integer quantisation).
+// Layers whose outputs leave the operator (base_remap, concat_features, the heads) keep their rows.
+// TGTC_NO_EQUALISE=1 packs the weights as given (development; tests/test_precision_robustness_gpu.py then fails).
+struct EqualisedNet {
+    std::vector<std::vector<float>> w, b;
+    std::vector<tgtc_linear> lin;
+    struct Cons {
+        int layer, col0;
+    };
+    static bool enabled() {
+        const char* e = std::getenv("TGTC_NO_EQUALISE");
+        return !(e && e[0] == '1');
+    }
+    void copy(const tgtc_linear* layers, int n) {
+        w.resize(n), b.resize(n), lin.resize(n);
+        for (int l = 0; l < n; ++l) {
+            w[l].assign(layers[l].weight, layers[l].weight + (size_t)layers[l].out_features * layers[l].in_features);
+            b[l].assign(layers[l].bias, layers[l].bias + layers[l].out_features);
+            lin[l] = tgtc_linear{w[l].data(), b[l].data(), layers[l].out_features, layers[l].in_features};
+        }
+    }
+    // rows of ReLU layer l against columns [col0, col0 + rows) of its consumers
+    void run(int l, std::initializer_list<Cons> cons) {
+        if (!enabled()) return;
+        const int n = lin[l].out_features, in = lin[l].in_features;
+        std::vector<int> k(n, 0);
+        for (int i = 0; i < n; ++i) {
+            float r1 = 0.0f, r2 = 0.0f;
+            for (int c = 0; c < in; ++c) r1 = std::fmax(r1, std::fabs(w[l][(size_t)i * in + c]));
+            for (const Cons& q : cons)
+                for (int r = 0; r < lin[q.layer].out_features; ++r)
+                    r2 = std::fmax(r2, std::fabs(w[q.layer][(size_t)r * lin[q.layer].in_features + q.col0 + i]));
+            if (r1 > 0.0f && r2 > 0.0f) k[i] = (int)std::nearbyint(0.5 * std::log2((double)r1 / (double)r2));
+        }
+        std::vector<int> sorted(k);
+        std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+        const int med = sorted[n / 2];   // only the spread matters: the layer keeps its typical activation scale
+        for (int i = 0; i < n; ++i) {
+            const int ki = std::max(-8, std::min(8, k[i] - med));
+            if (ki == 0) continue;
+            const float down = std::ldexp(1.0f, -ki), up = std::ldexp(1.0f, ki);
+            for (int c = 0; c < in; ++c) w[l][(size_t)i * in + c] *= down;
+            b[l][i] *= down;
+            for (const Cons& q : cons)
+                for (int r = 0; r < lin[q.layer].out_features; ++r)
+                    w[q.layer][(size_t)r * lin[q.layer].in_features + q.col0 + i] *= up;
+        }
+    }
+};
 
 struct PackedNet {
     std::vector<half_t> stream;  // fragments, chunk-padded

@@ -612,6 +612,13 @@ extern "C" int tgtc_style_create(const tgtc_linear* concat_layers, int n_concat,
             style_layers[i].in_features != want_s[i][1])
             return fail(TGTC_ERR_UNSUPPORTED, "style_create: style layer %d is %dx%d, kernels are built for %dx%d", i,
                         style_layers[i].out_features, style_layers[i].in_features, want_s[i][0], want_s[i][1]);
+    // hidden ReLU layers equalised by powers of two (mlp_pack.h, EqualisedNet); concat layer 4 (concat_features) and the rgb
+    // head keep their rows: their outputs leave the operators.  Inputs are cat(h, latent[, x]): h occupies columns 0..255.
+    EqualisedNet eqc, eqs;
+    eqc.copy(concat_layers, 5), eqs.copy(style_layers, 8);
+    for (int l = 0; l < 4; ++l) eqc.run(l, {{l + 1, 0}});
+    for (int l = 0; l < 7; ++l) eqs.run(l, {{l + 1, 0}});
+    concat_layers = eqc.lin.data(), style_layers = eqs.lin.data();
     const bool split = precision == TGTC_PREC_FP16X3;
     PackedNet pc = pack_layers(concat_specs(concat_layers), split);
     PackedNet ps = pack_layers(style_specs(style_layers), split);
