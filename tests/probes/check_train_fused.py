@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Development probe (GPU): the fused training path stage by stage against float64 autograd on the oracle's formulas.
+    1. forward outputs (rgb, sigma) and the activation stash (every layer, hi + lo planes, fragment order un-permuted)
+    2. the pre-activation gradients the input-gradient chain leaves in the workspace
+    3. the 24 parameter gradients
+"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from oracle import fields
+from tgtc_style_amd import fused_train, models, synth
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+H_COLS, Z_COLS = 2528, 2448
+h_layer = lambda l: 64 + 256 * l
+H_REMAP, H_F, H_DIR = 64 + 2048, 64 + 2048 + 256, 64 + 2048 + 256 + 128
+Z_REMAP, Z_F, Z_HEADS = 2048, 2304, 2432
+
+
+def act_col(ks, g, j):
+    return 32 * ks + (4 * g + j if j < 4 else 16 + 4 * g + (j - 4))
+
+
+def act_perm(n):      # fragment-order column c' -> logical feature
+    return np.array([act_col(c // 32, (c % 32) // 8, c % 8) for c in range(n)])
+
+
+class Args:
+    use_viewdir, act_type, embed_freq_coor, embed_freq_dir = True, "relu", 10, 4
+    netdepth = netdepth_fine = 8
+    netwidth = netwidth_fine = 256
+    style_D, vae_latent, precision = 8, 32, "fp16x3"
+
+
+rng = np.random.default_rng(0)
+pts = torch.from_numpy(rng.uniform(-1.2, 1.2, (M, 3)))
+dirs = torch.from_numpy(rng.uniform(-1, 1, (M, 3)))
+g_rgb = torch.from_numpy(rng.standard_normal((M, 3)).astype(np.float32) * 1e-3)
+g_sig = torch.from_numpy(rng.standard_normal(M).astype(np.float32) * 1e-5)
+sd = synth.nerf_state(1)
+T = lambda d, dt=torch.float32: {k: torch.from_numpy(np.ascontiguousarray(v)).to(dt) for k, v in d.items()}
+
+net = models.StyleNerf(Args, mode="fine")
+net.load_state_dict(T(sd))
+net = net.cuda()
+tr = fused_train.NerfTrainer()
+params = [p.detach().float().contiguous() for p in fused_train.mlp_parameters(net.net)]
+rgb, sigma = tr.forward(params, pts.cuda(), dirs.cuda())
+torch.cuda.synchronize()
+
+# ---- float64 reference with the intermediate activations kept
+w = {k: v.clone().requires_grad_() for k, v in T(sd, torch.float64).items()}
+pe = fields.posenc(pts, 10).to(torch.float32).double()
+de = fields.posenc(dirs, 4).to(torch.float32).double()
+lin = lambda n, x: torch.nn.functional.linear(x, w["net." + n + ".weight"], w["net." + n + ".bias"])
+zs, hs = [], []
+h = pe
+for i in range(8):
+    if i == 5:
+        h = torch.cat([pe, h], -1)
+    z = lin("base_layers.%d" % i, h)
+    z.retain_grad()
+    zs.append(z)
+    h = torch.relu(z)
+    hs.append(h)
+sig_ref = lin("sigma_layer", h).squeeze(-1)
+z_remap = lin("base_remap_layer", h)
+z_remap.retain_grad()
+remap = torch.relu(z_remap)
+z_f = lin("rgb_layers.0", torch.cat([remap, de], -1))
+z_f.retain_grad()
+f = torch.relu(z_f)
+z_rgb = lin("rgb_layers.1", f)
+z_rgb.retain_grad()
+rgb_ref = torch.sigmoid(z_rgb)
+rel = lambda a, b: float((a.double().cpu() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-30))
+print("forward: rgb rel %.2e  sigma rel %.2e" % (rel(rgb, rgb_ref), rel(sigma, sig_ref)))
+
+ws = tr.workspace(M, torch.device("cuda"))
+m_pad = (M + 127) // 128 * 128
+hi = ws[:m_pad * H_COLS * 2].view(torch.float16).reshape(m_pad, H_COLS)[:M].float().cpu()
+lo_off = (m_pad * H_COLS * 2 + 255) // 256 * 256
+lo = ws[lo_off:lo_off + m_pad * H_COLS * 2].view(torch.float16).reshape(m_pad, H_COLS)[:M].float().cpu()
+stash = hi.double() + lo.double()
+p256, p128 = act_perm(256), act_perm(128)
+for l in range(8):
+    got = torch.zeros(M, 256, dtype=torch.float64)
+    got[:, p256] = stash[:, h_layer(l):h_layer(l) + 256]
+    print("  stash h%d rel %.2e" % (l, rel(got, hs[l])))
+got = torch.zeros(M, 256, dtype=torch.float64); got[:, p256] = stash[:, H_REMAP:H_REMAP + 256]
+print("  stash remap rel %.2e" % rel(got, remap))
+got = torch.zeros(M, 128, dtype=torch.float64); got[:, p128] = stash[:, H_F:H_F + 128]
+print("  stash f rel %.2e" % rel(got, f))
+
+# ---- backward
+(rgb_ref * g_rgb.double()).sum().backward(retain_graph=True)
+(sig_ref * g_sig.double()).sum().backward()
+grads = tr.backward(params, rgb, g_rgb.cuda(), g_sig.cuda())
+torch.cuda.synchronize()
+tr.status()
+dz_off = (lo_off + m_pad * H_COLS * 2 + 255) // 256 * 256
+dz = ws[dz_off:dz_off + m_pad * Z_COLS * 4].view(torch.float32).reshape(m_pad, Z_COLS)[:M].double().cpu()
+heads = dz[:, Z_HEADS:Z_HEADS + 4]
+print("dgrad: heads d sigma rel %.2e  dz_rgb rel %.2e" % (rel(heads[:, 0], g_sig.double()), rel(heads[:, 1:4], z_rgb.grad)))
+got = torch.zeros(M, 128, dtype=torch.float64); got[:, p128] = dz[:, Z_F:Z_F + 128]
+print("  dz_f rel %.2e" % rel(got, z_f.grad))
+got = torch.zeros(M, 256, dtype=torch.float64); got[:, p256] = dz[:, Z_REMAP:Z_REMAP + 256]
+print("  dz_remap rel %.2e" % rel(got, z_remap.grad))
+for l in range(7, -1, -1):
+    got = torch.zeros(M, 256, dtype=torch.float64); got[:, p256] = dz[:, 256 * l:256 * l + 256]
+    print("  dz%d rel %.2e" % (l, rel(got, zs[l].grad)))
+names = ["base_layers.%d" % i for i in range(8)] + ["sigma_layer", "base_remap_layer", "rgb_layers.0", "rgb_layers.1"]
+for i, n in enumerate(names):
+    print("wgrad %-18s dW rel %.2e  db rel %.2e" % (n, rel(grads[2 * i], w["net." + n + ".weight"].grad), rel(grads[2 * i + 1], w["net." + n + ".bias"].grad)))

@@ -31,12 +31,12 @@ def test_config_file_and_defaults(tmp_path):
 
 
 def test_library_exports_every_header_symbol():
-    from tgtc_style_amd import hip, style2d  # noqa: F401  (style2d registers its header's symbols)
+    from tgtc_style_amd import fused_train, hip, style2d  # noqa: F401  (style2d / fused_train register their headers' symbols)
     assert os.path.exists(hip.LIB_PATH), "run __graft_entry__.build() first"
     assert hip.missing_symbols() == []
     lib = ctypes.CDLL(hip.LIB_PATH)
     declared = set()
-    for header in ("tgtc_hip.h", "tgtc_style2d.h"):
+    for header in ("tgtc_hip.h", "tgtc_style2d.h", "tgtc_train.h"):
         text = open(os.path.join(ROOT, "include", header)).read()
         declared |= set(re.findall(r"\b(tgtc_[a-z0-9_]+)\s*\(", text))
     declared -= {"tgtc_linear", "tgtc_named_tensor"}

@@ -1,0 +1,115 @@
+"""Fused training path of the NeRF MLP (include/tgtc_train.h, csrc/mlp_train.hip): StyleNerf.forward and its backward as
+three HIP launches per network instead of one GEMM launch per product (autograd_ops.py).
+
+    trainer = NerfTrainer()                                  # one per network (coarse, fine)
+    rgb, sigma = trainer.apply(module.net, pts, dirs)        # differentiable w.r.t. the 24 parameters of MLP_style
+
+`apply` is a torch.autograd.Function: forward = tgtc_trainer_forward (gather-pack of the current weights + the fused PE /
+12-layer kernel with activation stash), backward = tgtc_trainer_backward (input-gradient chain + weight gradients).  The
+sample points carry no gradient, as in the reference's training bodies (the samplers detach, utils.py:562-579)."""
+import ctypes
+
+import torch
+
+from . import hip
+
+c_int, c_int64, c_size_t, c_void_p = ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p
+_PTRS = ctypes.POINTER(c_void_p)
+
+SIGNATURES = {
+    "tgtc_trainer_create": [ctypes.POINTER(c_void_p)],
+    "tgtc_trainer_destroy": [c_void_p],
+    "tgtc_trainer_workspace_bytes": [c_int64],
+    "tgtc_trainer_forward": [c_void_p, _PTRS, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p],
+    "tgtc_trainer_backward": [c_void_p, _PTRS, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, _PTRS, c_void_p],
+    "tgtc_trainer_status": [c_void_p, c_void_p],
+}
+hip.register(SIGNATURES, {"tgtc_trainer_workspace_bytes": c_size_t})
+
+
+def mlp_parameters(net):
+    """The 24 tensors in the order of MLP_style.layers (models.py:93): weight, bias of base_layers[0..7], sigma_layer,
+    base_remap_layer, rgb_layers[0], rgb_layers[1]."""
+    layers = list(net.base_layers) + [net.sigma_layer, net.base_remap_layer] + list(net.rgb_layers)
+    out = []
+    for layer in layers:
+        out += [layer.weight, layer.bias]
+    return out
+
+
+def _table(tensors):
+    arr = (c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class NerfTrainer:
+    def __init__(self):
+        self.lib = hip.load()
+        h = c_void_p()
+        hip.check(self.lib.tgtc_trainer_create(ctypes.byref(h)))
+        self.handle = h
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.tgtc_trainer_destroy(self.handle)
+        except Exception:
+            pass
+
+    def workspace(self, M, device):
+        need = int(self.lib.tgtc_trainer_workspace_bytes(M))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def forward(self, params, pts, dirs):
+        M, dev = pts.shape[0], pts.device
+        ws = self.workspace(M, dev)
+        rgb = torch.empty(M, 3, device=dev, dtype=torch.float32)
+        sigma = torch.empty(M, device=dev, dtype=torch.float32)
+        hip.check(self.lib.tgtc_trainer_forward(self.handle, _table(params), hip.ptr(pts), hip.ptr(dirs), M, hip.ptr(ws), ws.numel(),
+                                                hip.ptr(rgb), hip.ptr(sigma), hip.stream()))
+        return rgb, sigma
+
+    def backward(self, params, rgb, d_rgb, d_sigma):
+        M = rgb.shape[0]
+        ws = self.workspace(M, rgb.device)
+        grads = [torch.empty_like(p, dtype=torch.float32) for p in params]
+        hip.check(self.lib.tgtc_trainer_backward(self.handle, _table(params), hip.ptr(rgb), hip.ptr(d_rgb), hip.ptr(d_sigma), M,
+                                                 hip.ptr(ws), ws.numel(), _table(grads), hip.stream()))
+        return grads
+
+    def status(self):
+        hip.check(self.lib.tgtc_trainer_status(self.handle, hip.stream()))
+
+    def apply(self, net, pts, dirs):
+        """pts, dirs: [..., 3] (any float dtype) -> rgb [..., 3], sigma [...]"""
+        lead = pts.shape[:-1]
+        p = pts.reshape(-1, 3).to(torch.float64).contiguous()
+        d = dirs.expand(*lead, 3).reshape(-1, 3).to(torch.float64).contiguous()
+        rgb, sigma = _NerfTrainFn.apply(self, p, d, *mlp_parameters(net))
+        return rgb.reshape(*lead, 3), sigma.reshape(*lead)
+
+
+class _NerfTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, trainer, pts, dirs, *params):
+        hip.require_gpu(pts, dirs, *params)
+        ps = [p.detach().float().contiguous() for p in params]
+        rgb, sigma = trainer.forward(ps, pts, dirs)
+        ctx.trainer, ctx.ps = trainer, ps
+        ctx.save_for_backward(rgb)
+        ctx.mark_non_differentiable()
+        return rgb, sigma
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_sigma):
+        (rgb,) = ctx.saved_tensors
+        M = rgb.shape[0]
+        d_rgb = torch.zeros_like(rgb) if d_rgb is None else d_rgb.float().contiguous()
+        d_sigma = torch.zeros(M, device=rgb.device) if d_sigma is None else d_sigma.float().contiguous()
+        grads = ctx.trainer.backward(ctx.ps, rgb, d_rgb, d_sigma)
+        return (None, None, None) + tuple(grads)
