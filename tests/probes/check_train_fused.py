@@ -78,18 +78,19 @@ print("forward: rgb rel %.2e  sigma rel %.2e" % (rel(rgb, rgb_ref), rel(sigma, s
 
 ws = tr.workspace(M, torch.device("cuda"))
 m_pad = (M + 127) // 128 * 128
-hi = ws[:m_pad * H_COLS * 2].view(torch.float16).reshape(m_pad, H_COLS)[:M].float().cpu()
+hi = ws[:m_pad * H_COLS * 2].view(torch.float16).float().cpu()
 lo_off = (m_pad * H_COLS * 2 + 255) // 256 * 256
-lo = ws[lo_off:lo_off + m_pad * H_COLS * 2].view(torch.float16).reshape(m_pad, H_COLS)[:M].float().cpu()
-stash = hi.double() + lo.double()
+lo = ws[lo_off:lo_off + m_pad * H_COLS * 2].view(torch.float16).float().cpu()
+flat = hi.double() + lo.double()
+seg = lambda buf, col0, width: buf[col0 * m_pad: col0 * m_pad + m_pad * width].reshape(m_pad, width)[:M]     # segment-major planes
 p256, p128 = act_perm(256), act_perm(128)
 for l in range(8):
     got = torch.zeros(M, 256, dtype=torch.float64)
-    got[:, p256] = stash[:, h_layer(l):h_layer(l) + 256]
+    got[:, p256] = seg(flat, h_layer(l), 256)
     print("  stash h%d rel %.2e" % (l, rel(got, hs[l])))
-got = torch.zeros(M, 256, dtype=torch.float64); got[:, p256] = stash[:, H_REMAP:H_REMAP + 256]
+got = torch.zeros(M, 256, dtype=torch.float64); got[:, p256] = seg(flat, H_REMAP, 256)
 print("  stash remap rel %.2e" % rel(got, remap))
-got = torch.zeros(M, 128, dtype=torch.float64); got[:, p128] = stash[:, H_F:H_F + 128]
+got = torch.zeros(M, 128, dtype=torch.float64); got[:, p128] = seg(flat, H_F, 128)
 print("  stash f rel %.2e" % rel(got, f))
 
 # ---- backward
@@ -99,16 +100,17 @@ grads = tr.backward(params, rgb, g_rgb.cuda(), g_sig.cuda())
 torch.cuda.synchronize()
 tr.status()
 dz_off = (lo_off + m_pad * H_COLS * 2 + 255) // 256 * 256
-dz = ws[dz_off:dz_off + m_pad * Z_COLS * 4].view(torch.float32).reshape(m_pad, Z_COLS)[:M].double().cpu()
-heads = dz[:, Z_HEADS:Z_HEADS + 4]
+dz = ws[dz_off:dz_off + m_pad * Z_COLS * 4].view(torch.float32).double().cpu()
+heads = seg(dz, Z_HEADS, 16)[:, :4]
 print("dgrad: heads d sigma rel %.2e  dz_rgb rel %.2e" % (rel(heads[:, 0], g_sig.double()), rel(heads[:, 1:4], z_rgb.grad)))
-got = torch.zeros(M, 128, dtype=torch.float64); got[:, p128] = dz[:, Z_F:Z_F + 128]
+got = torch.zeros(M, 128, dtype=torch.float64); got[:, p128] = seg(dz, Z_F, 128)
 print("  dz_f rel %.2e" % rel(got, z_f.grad))
-got = torch.zeros(M, 256, dtype=torch.float64); got[:, p256] = dz[:, Z_REMAP:Z_REMAP + 256]
+got = torch.zeros(M, 256, dtype=torch.float64); got[:, p256] = seg(dz, Z_REMAP, 256)
 print("  dz_remap rel %.2e" % rel(got, z_remap.grad))
 for l in range(7, -1, -1):
-    got = torch.zeros(M, 256, dtype=torch.float64); got[:, p256] = dz[:, 256 * l:256 * l + 256]
+    got = torch.zeros(M, 256, dtype=torch.float64); got[:, p256] = seg(dz, 256 * l, 256)
     print("  dz%d rel %.2e" % (l, rel(got, zs[l].grad)))
 names = ["base_layers.%d" % i for i in range(8)] + ["sigma_layer", "base_remap_layer", "rgb_layers.0", "rgb_layers.1"]
 for i, n in enumerate(names):
     print("wgrad %-18s dW rel %.2e  db rel %.2e" % (n, rel(grads[2 * i], w["net." + n + ".weight"].grad), rel(grads[2 * i + 1], w["net." + n + ".bias"].grad)))
+

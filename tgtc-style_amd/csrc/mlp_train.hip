@@ -16,6 +16,7 @@
 #include "../../include/tgtc_train.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -115,7 +116,7 @@ struct FwdArgs {
     long long M;
     const double* pts;     // [M,3]
     const double* dirs;    // [M,3]
-    half_t* h_hi;          // [M_pad][H_COLS]
+    half_t* h_hi;          // segments of [M_pad][width] (train_layouts.h)
     half_t* h_lo;
     unsigned long long* gates;   // [kGateLayers][M_pad / 16][64]
     long long n_tiles;     // M_pad / 16
@@ -147,12 +148,15 @@ __device__ __forceinline__ unsigned long long gate_word(const half8 (&h)[KS][1])
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// this lane's eight values of every k-step of a finished KS-k-step feature set -> its sample's row of the segment at col0
 template <int KS>
-__device__ __forceinline__ void stash_set(half_t* row_hi, half_t* row_lo, int col0, int g, const half8 (&h)[KS][1], const half8 (&l)[KS][1]) {
+__device__ __forceinline__ void stash_set(half_t* hi, half_t* lo, long long m_pad, long long row, int col0, int g, const half8 (&h)[KS][1],
+                                          const half8 (&l)[KS][1]) {
+    const size_t at = seg_at(col0, 32 * KS, m_pad, row) + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        *reinterpret_cast<half8*>(row_hi + col0 + 32 * ks + 8 * g) = h[ks][0];
-        *reinterpret_cast<half8*>(row_lo + col0 + 32 * ks + 8 * g) = l[ks][0];
+        *reinterpret_cast<half8*>(hi + at + 32 * ks) = h[ks][0];
+        *reinterpret_cast<half8*>(lo + at + 32 * ks) = l[ks][0];
     }
 }
 
@@ -185,12 +189,11 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_forward_kernel(Fwd
 
     // this lane's sample row of the stash (rows up to M_pad exist: tail lanes store their duplicate of the last sample,
     // the backward gives those rows zero gradients)
-    half_t* const row_hi = a.h_hi + (size_t)(s_wave + n) * H_COLS;
-    half_t* const row_lo = a.h_lo + (size_t)(s_wave + n) * H_COLS;
+    const long long m_pad = a.n_tiles * 16, row = s_wave + n;
     unsigned long long* const gate_lane = a.gates + (size_t)tile * 64 + lane;
     auto gate_out = [&](int layer, unsigned long long w) { gate_lane[(size_t)layer * a.n_tiles * 64] = w; };
-    stash_set<2>(row_hi, row_lo, H_PE, g, pe_h, pe_l);
-    stash_set<1>(row_hi, row_lo, H_DIR, g, de_h, de_l);
+    stash_set<2>(a.h_hi, a.h_lo, m_pad, row, H_PE, g, pe_h, pe_l);
+    stash_set<1>(a.h_hi, a.h_lo, m_pad, row, H_DIR, g, de_h, de_l);
 
     const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * g);
     ws.start();
@@ -206,7 +209,7 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_forward_kernel(Fwd
     };
     // a finished 256-wide layer: its fragments ARE the stash rows (fragment order), its gates one 64-bit word per lane
     auto keep = [&](int layer, int col0, const half8 (&h)[8][1], const half8 (&l)[8][1]) {
-        stash_set<8>(row_hi, row_lo, col0, g, h, l);
+        stash_set<8>(a.h_hi, a.h_lo, m_pad, row, col0, g, h, l);
         gate_out(layer, gate_word<8>(h));
     };
 
@@ -249,7 +252,7 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_forward_kernel(Fwd
             store_act<C, rt, decltype(h_)::value>(acc, Zh[rt / 2][0], Zl[rt / 2][0]);
         });
     }
-    stash_set<4>(row_hi, row_lo, H_F, g, Zh, Zl);
+    stash_set<4>(a.h_hi, a.h_lo, m_pad, row, H_F, g, Zh, Zl);
     gate_out(9, gate_word<4>(Zh));
     dense_layer<C, L::frag0(11), 4, 1, L::bias0(11)>(ws, bias_lane, Zh, Zl, [&](auto, auto, auto h_, const float4v& acc) {
         constexpr int hf = decltype(h_)::value;
@@ -346,7 +349,7 @@ struct BwdArgs {
     const float* d_sigma;    // [M]   dL/d sigma
     const unsigned long long* gates;
     long long n_tiles;
-    float* dz;               // [M_pad][Z_COLS]
+    float* dz;               // segments of [M_pad][width] (train_layouts.h)
     unsigned* maxima;        // [11] bit patterns of max |dz| per dZ segment (dz0..7, remap, f, heads); non-negative floats order as ints
     unsigned* status;        // [1]  set to 1 if a scaled gradient left the fp16 range
 };
@@ -377,19 +380,21 @@ __device__ __forceinline__ void split_pair_signed(float v0, float v1, unsigned& 
 // the next layer at scale 2^e_out.  `pend` carries the first half's pair until the second completes the 16-byte store.
 template <int RT, int HALF, bool OPERAND>
 __device__ __forceinline__ void dgrad_epi(const float4v& acc, unsigned long long gate, float s_true, float s_op, float& m, float (&pend)[2],
-                                          float* row_dz, int col0, int g, half8& oh, half8& ol) {
+                                          float* seg_row, int g, half8& oh, half8& ol) {
     constexpr int ks = RT / 2, e0 = (RT & 1) * 4 + 2 * HALF;
     constexpr int bit0 = 8 * (ks & 3) + (e0 >> 1), bit1 = bit0 + 4;
     const int word = (int)(ks < 4 ? (unsigned)gate : (unsigned)(gate >> 32));
     const int k0 = __builtin_amdgcn_sbfe(word, bit0, 1), k1 = __builtin_amdgcn_sbfe(word, bit1, 1);   // 0 / -1
-    const float v0 = __builtin_bit_cast(float, __builtin_bit_cast(int, acc[2 * HALF]) & k0);
-    const float v1 = __builtin_bit_cast(float, __builtin_bit_cast(int, acc[2 * HALF + 1]) & k1);
+    // (copies first: __builtin_bit_cast applied directly to a vector ELEMENT reads element 0 whatever the index -- hipcc 7.2)
+    const float a0 = acc[2 * HALF], a1 = acc[2 * HALF + 1];
+    const float v0 = __builtin_bit_cast(float, __builtin_bit_cast(int, a0) & k0);
+    const float v1 = __builtin_bit_cast(float, __builtin_bit_cast(int, a1) & k1);
     const float t0 = v0 * s_true, t1 = v1 * s_true;
     m = fmaxf(m, fmaxf(fabsf(t0), fabsf(t1)));
     if constexpr (HALF == 0) {
         pend[0] = t0, pend[1] = t1;
     } else {
-        *reinterpret_cast<float4v*>(row_dz + col0 + 32 * ks + 8 * g + 4 * (RT & 1)) = float4v{pend[0], pend[1], t0, t1};
+        *reinterpret_cast<float4v*>(seg_row + 32 * ks + 8 * g + 4 * (RT & 1)) = float4v{pend[0], pend[1], t0, t1};
     }
     if constexpr (OPERAND) {
         unsigned hpk, lpk;
@@ -435,9 +440,10 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
         lds_dma16(a.zero_bias + (j * C::NWAVES + wave) * 1024 + lane * 16, smem + C::RING_BYTES + (j * C::NWAVES + wave) * 1024);
     ws.prologue();
 
-    float* const row_dz = a.dz + (size_t)s * Z_COLS;     // rows up to M_pad exist; dead samples carry zeros
+    const long long m_pad = a.n_tiles * 16;               // rows up to M_pad exist; dead samples carry zeros
+    auto seg_row = [&](int col0, int width) { return a.dz + seg_at(col0, width, m_pad, s); };
     // heads: true values to the stash (16 floats: [d sigma, dz rgb, 0 ...]), tile maximum -> first scale
-    *reinterpret_cast<float4v*>(row_dz + Z_HEADS + 4 * g) = g == 0 ? float4v{hd[0], hd[1], hd[2], hd[3]} : float4v{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<float4v*>(seg_row(Z_HEADS, 16) + 4 * g) = g == 0 ? float4v{hd[0], hd[1], hd[2], hd[3]} : float4v{0.f, 0.f, 0.f, 0.f};
     float m = wave_max(fmaxf(fmaxf(fabsf(hd[0]), fabsf(hd[1])), fmaxf(fabsf(hd[2]), fabsf(hd[3]))));
     if (lane == 0) atomicMax(a.maxima + 10, __builtin_bit_cast(unsigned, m));
     int e_in = scale_exp(m, 0);
@@ -475,9 +481,10 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
         m = 0.f;
         {
             const float s_true = pow2f(-e_in), s_op = pow2f(e_out - e_in);
+            float* const zrow = seg_row(Z_F, 128);
             dense_layer<C, dgrad_frag0(0), 1, 8, 0>(ws, bias_lane, Bh, Bl, [&](auto rt_, auto, auto h_, const float4v& acc) {
                 constexpr int rt = decltype(rt_)::value, hf = decltype(h_)::value;
-                dgrad_epi<rt, hf, true>(acc, gw[9], s_true, s_op, m, pend, row_dz, Z_F, g, Zh[rt / 2][0], Zl[rt / 2][0]);
+                dgrad_epi<rt, hf, true>(acc, gw[9], s_true, s_op, m, pend, zrow, g, Zh[rt / 2][0], Zl[rt / 2][0]);
             });
         }
         e_next = close(9, m, e_out);
@@ -485,9 +492,10 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
         e_in = e_out, e_out = e_next;
         {
             const float s_true = pow2f(-e_in), s_op = pow2f(e_out - e_in);
+            float* const zrow = seg_row(Z_REMAP, 256);
             dense_layer<C, dgrad_frag0(1), 4, 16, 0>(ws, bias_lane, Zh, Zl, [&](auto rt_, auto, auto h_, const float4v& acc) {
                 constexpr int rt = decltype(rt_)::value, hf = decltype(h_)::value;
-                dgrad_epi<rt, hf, true>(acc, gw[8], s_true, s_op, m, pend, row_dz, Z_REMAP, g, Yh[rt / 2][0], Yl[rt / 2][0]);
+                dgrad_epi<rt, hf, true>(acc, gw[8], s_true, s_op, m, pend, zrow, g, Yh[rt / 2][0], Yl[rt / 2][0]);
             });
         }
         e_next = close(8, m, e_out);
@@ -500,9 +508,10 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
         for (int k = 0; k < 8; ++k) Bh[k][0] = Yh[k][0], Bl[k][0] = Yl[k][0];
         heads_frag(e_in, Bh[8][0], Bl[8][0]);
         const float s_true = pow2f(-e_in), s_op = pow2f(e_out - e_in);
+        float* const zrow = seg_row(z_layer(7), 256);
         dense_layer<C, dgrad_frag0(2), 9, 16, 0>(ws, bias_lane, Bh, Bl, [&](auto rt_, auto, auto h_, const float4v& acc) {
             constexpr int rt = decltype(rt_)::value, hf = decltype(h_)::value;
-            dgrad_epi<rt, hf, true>(acc, gw[7], s_true, s_op, m, pend, row_dz, z_layer(7), g, Xh[rt / 2][0], Xl[rt / 2][0]);
+            dgrad_epi<rt, hf, true>(acc, gw[7], s_true, s_op, m, pend, zrow, g, Xh[rt / 2][0], Xl[rt / 2][0]);
         });
     }
     e_next = close(7, m, e_out);
@@ -512,9 +521,10 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
         constexpr bool last = decltype(last_)::value;
         e_in = e_out, e_out = e_next;
         const float s_true = pow2f(-e_in), s_op = pow2f(e_out - e_in);
+        float* const zrow = seg_row(z_layer(l_out), 256);
         dense_layer<C, dgrad_frag0(d), 8, 16, 0>(ws, bias_lane, Ih, Il, [&](auto rt_, auto, auto h_, const float4v& acc) {
             constexpr int rt = decltype(rt_)::value, hf = decltype(h_)::value;
-            dgrad_epi<rt, hf, !last>(acc, gw[l_out], s_true, s_op, m, pend, row_dz, z_layer(l_out), g, Oh[rt / 2][0], Ol[rt / 2][0]);
+            dgrad_epi<rt, hf, !last>(acc, gw[l_out], s_true, s_op, m, pend, zrow, g, Oh[rt / 2][0], Ol[rt / 2][0]);
         });
         e_next = close(l_out, m, e_out);
     };
@@ -548,6 +558,8 @@ struct WgradArgs {
     const float* dz;
     const unsigned* maxima;          // per dZ segment (see BwdArgs)
     long long steps;                 // M_pad / 32
+    long long m_pad;
+    int ablate;                      // development (TGTC_WGRAD_ABLATE): 1 no global loads after the first, 2 no LDS stores, 4 no reads / MFMAs
     const short* unperm;             // per job: [128] row map then [320] column map (logical index or -1)
     float* grads[24];                // dW (2 * layer) and db (2 * layer + 1) of the twelve linears, zero-filled by the caller
     int chunk0[kWgradJobs + 1];      // workgroup ranges of the jobs
@@ -560,7 +572,7 @@ constexpr int kWgLdsBytes = 32 * (wg_stride(kWgMaxN) + wg_stride(kWgMaxK)) * 2 *
 static_assert(kWgLdsBytes <= 160 * 1024, "LDS");
 
 __device__ __forceinline__ int seg_of_zcol(int z_col) {
-    return z_col >= Z_HEADS ? 10 : z_col >= Z_F ? 9 : z_col >= Z_REMAP ? 8 : z_col / 256;
+    return z_col == Z_HEADS ? 10 : z_col == Z_F ? 9 : z_col == Z_REMAP ? 8 : z_col / 256;
 }
 
 // 4 samples x 16 features block of a row-major [sample][feature] fp16 image, transposed: lane i of each 16-lane group gets
@@ -587,122 +599,121 @@ __device__ __forceinline__ void tr_wait(TrQuad& r) {
 __device__ __forceinline__ half8 tr_hi(const TrQuad& r) { return __builtin_bit_cast(half8, u4{r.h0[0], r.h0[1], r.h1[0], r.h1[1]}); }
 __device__ __forceinline__ half8 tr_lo(const TrQuad& r) { return __builtin_bit_cast(half8, u4{r.l0[0], r.l0[1], r.l1[0], r.l1[1]}); }
 
-template <int KT>
+// N rows of dW (a dZ slice N wide), K0 + K1 input columns (two H segments), all compile-time: every staging load is
+// unconditional and issued back to back (a load behind a lane-dependent branch made hipcc wait for the previous one first:
+// three memory round trips per step), out-of-range threads re-read a valid unit and skip the LDS store.
+template <int N, int K0, int K1>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgradJob& J, int job, long long step0, long long step1, char* smem) {
+    constexpr int KT = (K0 + K1) / 16, NT = N / 16;
+    constexpr int SA = wg_stride(N), SB = wg_stride(K0 + K1);   // halves per image row
+    constexpr int A_UPR = N / 4, A_UNITS = 32 * A_UPR, A_PER = (A_UNITS + 511) / 512;      // 16-byte units: per row, per step, per thread
+    constexpr int B0_UPR = K0 / 8, B0_UNITS = 32 * B0_UPR, B0_PER = (B0_UNITS + 511) / 512;
+    constexpr int B1_UPR = K1 ? K1 / 8 : 1, B1_UNITS = K1 ? 32 * B1_UPR : 0;
+    static_assert(B1_UNITS <= 512 && A_PER <= 2 && B0_PER <= 2, "staging plan");
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int n = J.n, k_total = J.k_n[0] + J.k_n[1];
-    const int sa = wg_stride(n), sb = wg_stride(k_total);   // halves per image row
     half_t* const Ahi = reinterpret_cast<half_t*>(smem);
-    half_t* const Alo = Ahi + 32 * sa;
-    half_t* const Bhi = Alo + 32 * sa;
-    half_t* const Blo = Bhi + 32 * sb;
-    const int NT = n / 16;
+    half_t* const Alo = Ahi + 32 * SA;
+    half_t* const Bhi = Alo + 32 * SA;
+    half_t* const Blo = Bhi + 32 * SB;
 
     // scale of the dZ operand: a power of two that brings the segment maximum to ~2^10
     const unsigned mb = a.maxima[seg_of_zcol(J.z_col)];
     const int e_sc = mb == 0 ? 0 : 10 - ((int)(mb >> 23) - 127);
     const float sc = pow2f(e_sc);
 
-    constexpr int NPW = 1;            // row tiles per wave: wave w owns row tile w of the job (jobs have at most 8)
-    float4v acc[NPW][KT];
+    float4v acc[KT];
 #pragma unroll
-    for (int i = 0; i < NPW; ++i)
-#pragma unroll
-        for (int j = 0; j < KT; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < KT; ++j) acc[j] = float4v{0.f, 0.f, 0.f, 0.f};
     float4v bsum = float4v{0.f, 0.f, 0.f, 0.f};
 
-    // staging maps (16-byte units).  dZ: n/4 units per row; this thread's column unit is the same for all its rows
-    const int a_upr = n / 4, a_units = 32 * a_upr;
-    const int b0_upr = J.k_n[0] / 8, b1_upr = J.k_n[1] / 8;
-    const int b0_units = 32 * b0_upr, b1_units = 32 * b1_upr;
-    float4v ra[2];
-    u4 rb0h[2], rb0l[2], rb1h, rb1l;
-
-    auto load_step = [&](long long step) {
-        const long long r0 = step * 32;
+    // per-thread source pointers of step `step0`, advanced by 32 rows per step
+    const float* pa[A_PER];
+    const half_t *pb0h[B0_PER], *pb0l[B0_PER], *pb1h = nullptr, *pb1l = nullptr;
+    int la[A_PER], lb0[B0_PER], lb1 = 0;       // LDS offsets (halves); -1: this thread has no such unit
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int u = t + 512 * i;
-            if (u < a_units) ra[i] = *reinterpret_cast<const float4v*>(a.dz + (size_t)(r0 + u / a_upr) * Z_COLS + J.z_col + 4 * (u % a_upr));
-        }
+    for (int i = 0; i < A_PER; ++i) {
+        const int u = t + 512 * i, ue = u < A_UNITS ? u : u % A_UNITS;
+        pa[i] = a.dz + seg_at(J.z_col, J.z_n, a.m_pad, step0 * 32 + ue / A_UPR) + J.n0 + 4 * (ue % A_UPR);
+        la[i] = u < A_UNITS ? (u / A_UPR) * SA + 4 * (u % A_UPR) : -1;
+    }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int u = t + 512 * i;
-            if (u < b0_units) {
-                const size_t off = (size_t)(r0 + u / b0_upr) * H_COLS + J.k_col[0] + 8 * (u % b0_upr);
-                rb0h[i] = *reinterpret_cast<const u4*>(a.h_hi + off), rb0l[i] = *reinterpret_cast<const u4*>(a.h_lo + off);
-            }
+    for (int i = 0; i < B0_PER; ++i) {
+        const int u = t + 512 * i, ue = u < B0_UNITS ? u : u % B0_UNITS;
+        const size_t off = seg_at(J.k_col[0], K0, a.m_pad, step0 * 32 + ue / B0_UPR) + 8 * (ue % B0_UPR);
+        pb0h[i] = a.h_hi + off, pb0l[i] = a.h_lo + off;
+        lb0[i] = u < B0_UNITS ? (u / B0_UPR) * SB + 8 * (u % B0_UPR) : -1;
+    }
+    if constexpr (K1 > 0) {
+        const int ue = t % B1_UNITS;
+        const size_t off = seg_at(J.k_col[1], K1, a.m_pad, step0 * 32 + ue / B1_UPR) + 8 * (ue % B1_UPR);
+        pb1h = a.h_hi + off, pb1l = a.h_lo + off;
+        lb1 = t < B1_UNITS ? (t / B1_UPR) * SB + K0 + 8 * (t % B1_UPR) : -1;
+    }
+    float4v ra[A_PER];
+    u4 rb0h[B0_PER], rb0l[B0_PER], rb1h = u4{0, 0, 0, 0}, rb1l = u4{0, 0, 0, 0};
+    auto load_step = [&]() {    // the step the pointers stand on; then move them on
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) ra[i] = *reinterpret_cast<const float4v*>(pa[i]), pa[i] += 32 * (size_t)J.z_n;
+#pragma unroll
+        for (int i = 0; i < B0_PER; ++i) {
+            rb0h[i] = *reinterpret_cast<const u4*>(pb0h[i]), rb0l[i] = *reinterpret_cast<const u4*>(pb0l[i]);
+            pb0h[i] += 32 * K0, pb0l[i] += 32 * K0;
         }
-        if (t < b1_units) {
-            const size_t off = (size_t)(r0 + t / b1_upr) * H_COLS + J.k_col[1] + 8 * (t % b1_upr);
-            rb1h = *reinterpret_cast<const u4*>(a.h_hi + off), rb1l = *reinterpret_cast<const u4*>(a.h_lo + off);
+        if constexpr (K1 > 0) {
+            rb1h = *reinterpret_cast<const u4*>(pb1h), rb1l = *reinterpret_cast<const u4*>(pb1l);
+            pb1h += 32 * K1, pb1l += 32 * K1;
         }
     };
     auto store_step = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int u = t + 512 * i;
-            if (u < a_units) {
+        for (int i = 0; i < A_PER; ++i) {
+            if (la[i] >= 0) {
                 const float4v v = ra[i];
                 bsum += v;
                 unsigned h01, l01, h23, l23;
                 split_pair_signed(v[0] * sc, v[1] * sc, h01, l01);
                 split_pair_signed(v[2] * sc, v[3] * sc, h23, l23);
-                const int off = (u / a_upr) * sa + 4 * (u % a_upr);
-                *reinterpret_cast<u2w*>(Ahi + off) = u2w{h01, h23};
-                *reinterpret_cast<u2w*>(Alo + off) = u2w{l01, l23};
+                *reinterpret_cast<u2w*>(Ahi + la[i]) = u2w{h01, h23};
+                *reinterpret_cast<u2w*>(Alo + la[i]) = u2w{l01, l23};
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int u = t + 512 * i;
-            if (u < b0_units) {
-                const int off = (u / b0_upr) * sb + 8 * (u % b0_upr);
-                *reinterpret_cast<u4*>(Bhi + off) = rb0h[i], *reinterpret_cast<u4*>(Blo + off) = rb0l[i];
-            }
-        }
-        if (t < b1_units) {
-            const int off = (t / b1_upr) * sb + J.k_n[0] + 8 * (t % b1_upr);
-            *reinterpret_cast<u4*>(Bhi + off) = rb1h, *reinterpret_cast<u4*>(Blo + off) = rb1l;
-        }
+        for (int i = 0; i < B0_PER; ++i)
+            if (lb0[i] >= 0) *reinterpret_cast<u4*>(Bhi + lb0[i]) = rb0h[i], *reinterpret_cast<u4*>(Blo + lb0[i]) = rb0l[i];
+        if constexpr (K1 > 0)
+            if (lb1 >= 0) *reinterpret_cast<u4*>(Bhi + lb1) = rb1h, *reinterpret_cast<u4*>(Blo + lb1) = rb1l;
     };
 
     // transposed-read addresses: lane group G = lane >> 4 takes samples 8G .. 8G+7 (two blocks of 4), lane 4q + p of the
     // group points at row q of the block, features 4p .. 4p+3 of the 16-feature tile
     const int G = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    const int a_row = (8 * G + q) * sa + 4 * p, b_row = (8 * G + q) * sb + 4 * p;
-    load_step(step0);
+    const int nt = wave < NT ? wave : 0;        // idle waves read tile 0 and discard (EXEC stays full for the reads)
+    const half_t* const a_hi = Ahi + (8 * G + q) * SA + 4 * p + 16 * nt;
+    const half_t* const a_lo = Alo + (8 * G + q) * SA + 4 * p + 16 * nt;
+    const int b_row = (8 * G + q) * SB + 4 * p;
+
+    load_step();
     for (long long step = step0; step < step1; ++step) {
         __syncthreads();          // everyone is done reading the previous step's images
-        store_step();
+        if (!(a.ablate & 2)) store_step();
         __syncthreads();
-        if (step + 1 < step1) load_step(step + 1);      // in flight while this step multiplies
-        TrQuad qa[NPW], qb[2];
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) {
-            const int nt = wave + 8 * i;
-            const int c0 = (nt < NT ? nt : 0) * 16;     // idle waves read tile 0 and discard (EXEC stays full for the reads)
-            tr_issue(qa[i], Ahi + a_row + c0, Alo + a_row + c0, 4 * sa);
-        }
-        tr_issue(qb[0], Bhi + b_row, Blo + b_row, 4 * sb);
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) tr_wait(qa[i]);
-        half8 ah[NPW], al[NPW];
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) ah[i] = tr_hi(qa[i]), al[i] = tr_lo(qa[i]);
+        if (step + 1 < step1 && !(a.ablate & 1)) load_step();      // in flight while this step multiplies
+        if (a.ablate & 4) continue;
+        TrQuad qa, qb[2];
+        tr_issue(qa, a_hi, a_lo, 4 * SA);
+        tr_issue(qb[0], Bhi + b_row, Blo + b_row, 4 * SB);
+        tr_wait(qa);
+        const half8 ah = tr_hi(qa), al = tr_lo(qa);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             tr_wait(qb[kt & 1]);
             const half8 bh = tr_hi(qb[kt & 1]), bl = tr_lo(qb[kt & 1]);
-            if (kt + 1 < KT) tr_issue(qb[(kt + 1) & 1], Bhi + b_row + 16 * (kt + 1), Blo + b_row + 16 * (kt + 1), 4 * sb);
+            if (kt + 1 < KT) tr_issue(qb[(kt + 1) & 1], Bhi + b_row + 16 * (kt + 1), Blo + b_row + 16 * (kt + 1), 4 * SB);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < NPW; ++i) {
-                acc[i][kt] = mfma16(ah[i], bh, acc[i][kt]);
-                acc[i][kt] = mfma16(al[i], bh, acc[i][kt]);
-                acc[i][kt] = mfma16(ah[i], bl, acc[i][kt]);
-            }
+            acc[kt] = mfma16(ah, bh, acc[kt]);
+            acc[kt] = mfma16(al, bh, acc[kt]);
+            acc[kt] = mfma16(ah, bl, acc[kt]);
         }
     }
 
@@ -713,26 +724,25 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgradJob& J
     float* const db = a.grads[2 * J.layer + 1];
     const int in_features = J.layer == 0 ? 63 : J.layer == 5 ? 319 : J.layer == 10 ? 283 : J.layer == 11 ? 128 : 256;
     const float inv = pow2f(-e_sc);
+    if (wave < NT) {
+        int nr[4], kc[KT];          // all map entries first (independent loads), then the atomics
 #pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        const int nt = wave + 8 * i;
-        if (nt >= NT) continue;
+        for (int r = 0; r < 4; ++r) nr[r] = nmap[16 * wave + 4 * (lane >> 4) + r];   // (the job's map already starts at its n0)
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            const int kc = kmap[16 * kt + (lane & 15)];
+        for (int kt = 0; kt < KT; ++kt) kc[kt] = kmap[16 * kt + (lane & 15)];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int nr = nmap[16 * nt + 4 * (lane >> 4) + r];   // (the job's map already starts at its n0)
-                if (nr >= 0 && kc >= 0) atomicAdd(dW + (size_t)nr * in_features + kc, acc[i][kt][r] * inv);
-            }
-        }
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (nr[r] >= 0 && kc[kt] >= 0) atomicAdd(dW + (size_t)nr[r] * in_features + kc[kt], acc[kt][r] * inv);
     }
     // db: this thread's four dZ columns (the same in every step)
+    if (la[0] >= 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (t >= a_units) break;
-        const int nr = nmap[4 * (t % a_upr) + i];
-        if (nr >= 0) atomicAdd(db + nr, bsum[i]);
+        for (int i = 0; i < 4; ++i) {
+            const int nr = nmap[4 * (t % A_UPR) + i];
+            if (nr >= 0) atomicAdd(db + nr, bsum[i]);
+        }
     }
 }
 
@@ -745,12 +755,13 @@ __global__ void __launch_bounds__(512, 2) train_wgrad_kernel(WgradArgs a) {
     const int nchunk = a.chunk0[job + 1] - a.chunk0[job], chunk = (int)blockIdx.x - a.chunk0[job];
     const long long step0 = a.steps * chunk / nchunk, step1 = a.steps * (chunk + 1) / nchunk;
     const WgradJob J = kWgradJob[job];
-    switch ((J.k_n[0] + J.k_n[1]) / 16) {
-        case 4: wgrad_body<4>(a, J, job, step0, step1, smem); break;      // layer 0: k = 64
-        case 20: wgrad_body<20>(a, J, job, step0, step1, smem); break;    // layer 5: k = 256 + 64
-        case 18: wgrad_body<18>(a, J, job, step0, step1, smem); break;    // rgb_layers.0: k = 256 + 32
-        case 8: wgrad_body<8>(a, J, job, step0, step1, smem); break;      // rgb_layers.1: k = 128
-        default: wgrad_body<16>(a, J, job, step0, step1, smem); break;    // k = 256
+    switch (J.layer) {
+        case 0: wgrad_body<128, 64, 0>(a, J, job, step0, step1, smem); break;
+        case 5: wgrad_body<128, 256, 64>(a, J, job, step0, step1, smem); break;
+        case 8: wgrad_body<16, 256, 0>(a, J, job, step0, step1, smem); break;
+        case 10: wgrad_body<128, 256, 32>(a, J, job, step0, step1, smem); break;
+        case 11: wgrad_body<16, 128, 0>(a, J, job, step0, step1, smem); break;
+        default: wgrad_body<128, 256, 0>(a, J, job, step0, step1, smem); break;
     }
 }
 
@@ -923,18 +934,15 @@ extern "C" int tgtc_trainer_backward(tgtc_trainer* tr, const float* const* param
 
     WgradArgs g{};
     g.h_hi = reinterpret_cast<const half_t*>(ws + w.h_hi), g.h_lo = reinterpret_cast<const half_t*>(ws + w.h_lo);
-    g.dz = reinterpret_cast<const float*>(ws + w.dz), g.maxima = maxima, g.steps = w.m_pad / 32;
+    g.dz = reinterpret_cast<const float*>(ws + w.dz), g.maxima = maxima, g.steps = w.m_pad / 32, g.m_pad = w.m_pad;
     g.unperm = reinterpret_cast<const short*>(tr->dev + tr->unperm_off);
+    if (const char* e = std::getenv("TGTC_WGRAD_ABLATE")) g.ablate = std::atoi(e);
     for (int i = 0; i < 24; ++i) g.grads[i] = grads[i];
-    // workgroups per job in proportion to its multiply count, ~288 in all (one per CU and a few to spare), never more than steps
-    int cost[kWgradJobs], total = 0;
-    for (int j = 0; j < kWgradJobs; ++j) total += cost[j] = (kWgradJob[j].n / 16) * ((kWgradJob[j].k_n[0] + kWgradJob[j].k_n[1]) / 16);
+    // A step costs every job about the same (it is bound by the round trip of its staging loads, not by its 12 .. 60 MFMAs
+    // per wave), so every job gets the same number of sample chunks: 21 jobs x 12 = 252 workgroups, one round on 256 CUs.
+    // (In proportion to the multiply count the two one-tile jobs ran all 4 096 steps in ONE workgroup: 4 ms.)
     g.chunk0[0] = 0;
-    for (int j = 0; j < kWgradJobs; ++j) {
-        long long c = std::max(1LL, (288LL * cost[j] + total / 2) / total);
-        c = std::min<long long>(c, g.steps);
-        g.chunk0[j + 1] = g.chunk0[j] + (int)c;
-    }
+    for (int j = 0; j < kWgradJobs; ++j) g.chunk0[j + 1] = g.chunk0[j] + (int)std::min<long long>(12, g.steps);
     TGTC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(train_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kWgLdsBytes));
     train_wgrad_kernel<<<(unsigned)g.chunk0[kWgradJobs], 512, kWgLdsBytes, st>>>(g);
     TGTC_LAUNCH_CHECK();

@@ -61,6 +61,9 @@ class NerfTrainer:
 
     def workspace(self, M, device):
         need = int(self.lib.tgtc_trainer_workspace_bytes(M))
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws

@@ -163,11 +163,19 @@ class StyleNerf(nn.Module):
                              enable_style=enable_style)
         self.net.precision = _precision_of(args, mode)
         self.enable_style = enable_style
+        self.fused_training, self._trainer = False, None
 
-    def trainable(self, on=True):
-        """Training side: forward through the differentiable layer-by-layer HIP dense layers whenever gradients are enabled
-        (the render paths stay on the fused kernels)."""
+    def trainable(self, on=True, fused=True):
+        """Training side: whenever gradients are enabled the forward becomes differentiable w.r.t. the 24 parameters (the
+        render paths stay on the fused forward-only kernels).  fused=True (default): the fused training path
+        (fused_train.py / csrc/mlp_train.hip: forward with activation stash, input-gradient chain and weight gradients as
+        three launches; returns the dict entries a training body reads -- rgb and sigma).  fused=False: the same arithmetic
+        layer by layer on differentiable HIP dense layers (autograd_ops.py), with every entry of the render-path dict."""
         self.net.differentiable = bool(on)
+        self.fused_training = bool(on and fused)
+        if self.fused_training and self._trainer is None:
+            from . import fused_train
+            self._trainer = fused_train.NerfTrainer()
         return self
 
     def set_enable_style(self, enable_style=False):
@@ -183,6 +191,9 @@ class StyleNerf(nn.Module):
         hip.require_gpu(pts)
         lib = hip.load()
         lead = pts.shape[:-1]
+        if self.net.wants_grad() and self.fused_training:
+            rgb, sigma = self._trainer.apply(self.net, pts.detach(), dirs.detach())      # train_tgtcs.py:234-236 reads rgb, sigma
+            return OrderedDict([('rgb', rgb), ('sigma', sigma)])
         if self.net.wants_grad():
             # training side (train_tgtcs.py:218-309): encodings from the HIP encoder (no gradient: the samplers are detached
             # in the reference too), then the differentiable layer-by-layer network

@@ -13,7 +13,8 @@ rd = torch.from_numpy(rng.uniform(-1, 1, (R, 3)) * [0.4, 0.4, 0.1] + [0, 0, -1.0
 gt = torch.from_numpy(rng.uniform(0.2, 0.8, (R, 3)).astype(np.float32)).cuda()
 m, mf = models.StyleNerf(bench.NetArgs, mode="coarse"), models.StyleNerf(bench.NetArgs, mode="fine")
 m.load_state_dict(bench.t_state(synth.nerf_state(0))), mf.load_state_dict(bench.t_state(synth.nerf_state(1)))
-m, mf = m.cuda().trainable(), mf.cuda().trainable()
+FUSED = os.environ.get("TGTC_TRAIN_UNFUSED") != "1"
+m, mf = m.cuda().trainable(fused=FUSED), mf.cuda().trainable(fused=FUSED)
 opt = torch.optim.Adam(list(m.parameters()) + list(mf.parameters()), lr=5e-4)
 for i in range(13):
     if i == 3:
@@ -22,4 +23,4 @@ for i in range(13):
 torch.cuda.synchronize()
 dt = (time.time() - t0) / 10
 samples = R * (64 + 128)
-print("origin_train_step: %d rays, %d network samples: %.1f ms per iteration (%.2f M samples/s), loss %.4f" % (R, samples, dt * 1e3, samples / dt / 1e6, r["loss"]))
+print(("fused " if FUSED else "unfused ") + "origin_train_step: %d rays, %d network samples: %.1f ms per iteration (%.2f M samples/s), loss %.4f" % (R, samples, dt * 1e3, samples / dt / 1e6, r["loss"]))
