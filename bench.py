@@ -260,16 +260,14 @@ def _torch_origin_train_step(m, mf, opt, ro, rd, gt, nc, nf, noise_std):
 
 def bench_train_step(steps, warmup, rays=1024):
     """one iteration of the reference's Origin_train body (coarse + fine losses, sigma noise, Adam) on
-    the differentiable HIP dense layers, with the same iteration in stock torch eager autograd beside it.  ms per iteration."""
+    the FUSED training kernels (fused_train.NerfTrainer: one forward kernel with the activation stash, one input-gradient
+    chain, one weight-gradient kernel per network), with the same iteration on the unfused per-layer HIP dense layers and in
+    stock torch eager autograd beside it.  ms per iteration."""
     from tgtc_style_amd import models, synth, training
     rng = np.random.default_rng(1)
     ro = torch.from_numpy(rng.uniform(-0.3, 0.3, (rays, 3))).cuda()
     rd = torch.from_numpy(rng.uniform(-1, 1, (rays, 3)) * [0.4, 0.4, 0.1] + [0, 0, -1.0]).cuda()
     gt = torch.from_numpy(rng.uniform(0.2, 0.8, (rays, 3)).astype(np.float32)).cuda()
-    m, mf = models.StyleNerf(NetArgs, mode="coarse"), models.StyleNerf(NetArgs, mode="fine")
-    m.load_state_dict(t_state(synth.nerf_state(0))), mf.load_state_dict(t_state(synth.nerf_state(1)))
-    m, mf = m.cuda().trainable(), mf.cuda().trainable()
-    opt = torch.optim.Adam(list(m.parameters()) + list(mf.parameters()), lr=5e-4)
 
     def timed(fn):
         for i in range(warmup + steps):
@@ -280,8 +278,16 @@ def bench_train_step(steps, warmup, rays=1024):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps * 1e3, r
 
-    ms, r = timed(lambda: training.origin_train_step(m, mf, opt, ro, rd, gt, 64, 64, 0., 1., sigma_noise_std=0.1))
-    assert np.isfinite(r["loss"])
+    def hip_iteration(fused):
+        m, mf = models.StyleNerf(NetArgs, mode="coarse"), models.StyleNerf(NetArgs, mode="fine")
+        m.load_state_dict(t_state(synth.nerf_state(0))), mf.load_state_dict(t_state(synth.nerf_state(1)))
+        m, mf = m.cuda().trainable(fused=fused), mf.cuda().trainable(fused=fused)
+        opt = torch.optim.Adam(list(m.parameters()) + list(mf.parameters()), lr=5e-4)
+        ms, r = timed(lambda: training.origin_train_step(m, mf, opt, ro, rd, gt, 64, 64, 0., 1., sigma_noise_std=0.1))
+        assert np.isfinite(r["loss"])
+        return ms
+
+    ms, ms_unfused = hip_iteration(True), hip_iteration(False)
     tm, tmf = _TorchNerf(synth.nerf_state(0)).cuda(), _TorchNerf(synth.nerf_state(1)).cuda()
     topt = torch.optim.Adam(list(tm.parameters()) + list(tmf.parameters()), lr=5e-4)
     ms_torch, loss_t = timed(lambda: _torch_origin_train_step(tm, tmf, topt, ro, rd, gt, 64, 64, 0.1))
@@ -290,16 +296,18 @@ def bench_train_step(steps, warmup, rays=1024):
     flop = float(FLOP_TRAIN_PER_SAMPLE) * samples
     achieved = flop / (ms * 1e-3) / 1e12
     return {"metric": "ms per Origin_train iteration (1024 rays, 64 coarse + 128 fine-pass network samples, forward + backward + Adam) "
-                      "on the differentiable HIP dense layers", "value": ms, "unit": "ms", "higher_is_better": False,
+                      "on the fused HIP training kernels", "value": ms, "unit": "ms", "higher_is_better": False,
             "steps": steps, "dtype": "fp16x3", "network_samples_per_s": samples / (ms * 1e-3),
             "flop_per_iter": flop,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP16_TFLOPS,
                          "note": "algorithmic flops of forward + input gradients + weight gradients (%.3f MFLOP per network sample) / wall "
                                  "time of the whole iteration, sampling, compositing and Adam included; fp16x3 issues 3 MFMA products per "
-                                 "algorithmic product" % (FLOP_TRAIN_PER_SAMPLE / 1e6)},
+                                 "algorithmic product; per-kernel times: profiles/r3_train_kernels.txt" % (FLOP_TRAIN_PER_SAMPLE / 1e6)},
             "comparator": {"what": "the same Origin_train iteration in stock torch-ROCm eager autograd (fp32 rocBLAS GEMMs, torch "
                                    "elementwise / cumprod / searchsorted kernels) on the same GPU, same rays; a baseline, not a target",
-                           "value": ms_torch, "unit": "ms", "speedup": ms_torch / ms}}
+                           "value": ms_torch, "unit": "ms", "speedup": ms_torch / ms},
+            "unfused": {"what": "the same iteration on the per-layer differentiable HIP dense layers (autograd_ops.py; round 2's path)",
+                        "value": ms_unfused, "unit": "ms", "speedup": ms_unfused / ms}}
 
 
 def make_renderer(precision, styled):
@@ -490,7 +498,7 @@ def main():
             if "trex_rays" in wanted:   # BASELINE config 4's frame on one GPU (its 8 ray ranges are this frame's slices)
                 cfg["trex_rays"] = dict(bench_frame(args.precision, 378, 504, short, 1),
                                         metric="rays/sec (128c+64f) on a whole trex 504x378 frame (190512 rays), one GPU")
-            if "train_step" in wanted:  # SURVEY 8f rank 4 (training side), unfused
+            if "train_step" in wanted:  # SURVEY 8f rank 4 (training side)
                 cfg["train_step"] = bench_train_step(6, 3)
             if cfg:
                 line["configs"] = cfg

@@ -154,10 +154,16 @@ def test_fused_training_path_matches_the_unfused_one():
         a, b = grads[True], grads[False]
         assert float((a[0] - b[0]).abs().max()) <= 2e-5 and float((a[1] - b[1]).abs().max()) <= 2e-5 * float(b[1].abs().max())
         for i, (ga, gb) in enumerate(zip(a[2], b[2])):
-            # the two forwards round differently at the 1e-7 level: among 4 097 x 2 432 ReLU units one or two pre-activations
-            # within rounding of zero gate differently, which moves single gradient entries by one sample's contribution
-            rel = (ga - gb).abs() / (float(gb.abs().max()) + 1e-30)
-            assert float((rel <= 3e-5).float().mean()) >= 0.999 and float(rel.max()) <= 5e-3, (M, i, float(rel.max()))
+            # The two forwards round differently at the 1e-7 level: among 4 097 x 2 432 ReLU units one or two pre-activations
+            # within rounding of zero gate differently.  Such a sample changes its own contribution to every layer below the
+            # flipped unit -- a RANK-ONE term dz[s] (x) h[s] per weight matrix, dense in the early layers.  So: the difference of
+            # the two gradients is at most eight rank-one terms (eight flipped samples; four seen at M = 4 097: singular values 3e-4 .. 9e-5, the fifth 1e-7) on top of 3e-5 of rounding, and small.
+            d, scale = (ga - gb).double(), float(gb.abs().max()) + 1e-30
+            assert float(d.abs().max()) <= 5e-3 * scale, (M, i, float(d.abs().max()) / scale)
+            if d.dim() == 2 and float(d.abs().max()) > 3e-5 * scale:
+                U, S, Vh = torch.linalg.svd(d, full_matrices=False)
+                d = d - (U[:, :8] * S[:8]) @ Vh[:8]
+                assert float(d.abs().max()) <= 3e-5 * scale, (M, i, float(d.abs().max()) / scale, S[:6].tolist())
 
 
 def test_style_mlp_gradients_match_the_oracle():

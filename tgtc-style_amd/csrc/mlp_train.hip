@@ -559,7 +559,6 @@ struct WgradArgs {
     const unsigned* maxima;          // per dZ segment (see BwdArgs)
     long long steps;                 // M_pad / 32
     long long m_pad;
-    int ablate;                      // development (TGTC_WGRAD_ABLATE): 1 no global loads after the first, 2 no LDS stores, 4 no reads / MFMAs
     const short* unperm;             // per job: [128] row map then [320] column map (logical index or -1)
     float* grads[24];                // dW (2 * layer) and db (2 * layer + 1) of the twelve linears, zero-filled by the caller
     int chunk0[kWgradJobs + 1];      // workgroup ranges of the jobs
@@ -696,10 +695,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgradJob& J
     load_step();
     for (long long step = step0; step < step1; ++step) {
         __syncthreads();          // everyone is done reading the previous step's images
-        if (!(a.ablate & 2)) store_step();
+        store_step();
         __syncthreads();
-        if (step + 1 < step1 && !(a.ablate & 1)) load_step();      // in flight while this step multiplies
-        if (a.ablate & 4) continue;
+        if (step + 1 < step1) load_step();      // in flight while this step multiplies
         TrQuad qa, qb[2];
         tr_issue(qa, a_hi, a_lo, 4 * SA);
         tr_issue(qb[0], Bhi + b_row, Blo + b_row, 4 * SB);
@@ -920,9 +918,19 @@ extern "C" int tgtc_trainer_backward(tgtc_trainer* tr, const float* const* param
     TGTC_HIP_CHECK(hipMemsetAsync(maxima, 0, 64, st));
     static const int shape[12][2] = {{256, 63}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 319}, {256, 256}, {256, 256},
                                      {1, 256},  {256, 256}, {128, 283}, {3, 128}};
-    for (int l = 0; l < 12; ++l) {
-        TGTC_HIP_CHECK(hipMemsetAsync(grads[2 * l], 0, (size_t)shape[l][0] * shape[l][1] * sizeof(float), st));
-        TGTC_HIP_CHECK(hipMemsetAsync(grads[2 * l + 1], 0, (size_t)shape[l][0] * sizeof(float), st));
+    {   // the weight-gradient kernel accumulates: zero-fill first (ONE fill when the caller laid the 24 tensors out back to back)
+        size_t bytes[24], total = 0;
+        bool packed = true;
+        for (int l = 0; l < 12; ++l) bytes[2 * l] = (size_t)shape[l][0] * shape[l][1] * sizeof(float), bytes[2 * l + 1] = (size_t)shape[l][0] * sizeof(float);
+        for (int i = 0; i < 24; ++i) {
+            if (i + 1 < 24 && reinterpret_cast<char*>(grads[i]) + bytes[i] != reinterpret_cast<char*>(grads[i + 1])) packed = false;
+            total += bytes[i];
+        }
+        if (packed) {
+            TGTC_HIP_CHECK(hipMemsetAsync(grads[0], 0, total, st));
+        } else {
+            for (int i = 0; i < 24; ++i) TGTC_HIP_CHECK(hipMemsetAsync(grads[i], 0, bytes[i], st));
+        }
     }
     char* ws = static_cast<char*>(workspace);
     BwdArgs b{};
@@ -936,7 +944,6 @@ extern "C" int tgtc_trainer_backward(tgtc_trainer* tr, const float* const* param
     g.h_hi = reinterpret_cast<const half_t*>(ws + w.h_hi), g.h_lo = reinterpret_cast<const half_t*>(ws + w.h_lo);
     g.dz = reinterpret_cast<const float*>(ws + w.dz), g.maxima = maxima, g.steps = w.m_pad / 32, g.m_pad = w.m_pad;
     g.unperm = reinterpret_cast<const short*>(tr->dev + tr->unperm_off);
-    if (const char* e = std::getenv("TGTC_WGRAD_ABLATE")) g.ablate = std::atoi(e);
     for (int i = 0; i < 24; ++i) g.grads[i] = grads[i];
     // A step costs every job about the same (it is bound by the round trip of its staging loads, not by its 12 .. 60 MFMAs
     // per wave), so every job gets the same number of sample chunks: 21 jobs x 12 = 252 workgroups, one round on 256 CUs.

@@ -18,8 +18,11 @@ struct FusedArgs {   // render_fused.hip
     const char* net_f;
     float* rgb;
     float* t;
+    float* ts_out;
 };
 int launch_fused_render(int prec_c, int prec_f, const FusedArgs& a, hipStream_t st);
+int launch_fused_depths(int prec_c, const FusedArgs& a, hipStream_t st);
+bool fused_depths_supports(int prec_c, int n_coarse, int n_fine);
 bool fused_render_supports(int prec_c, int prec_f, int n_coarse, int n_fine);
 
 int launch_composite(const float* rgb, const float* sigma, const float* ts, int64_t R, int N, float* rgb_exp,
@@ -78,7 +81,7 @@ extern "C" int tgtc_render_rays_plain(const tgtc_net* coarse, const tgtc_net* fi
         fused_render_supports(coarse->precision, fine->precision, n_coarse, n_fine)) {
         if (R == 0) return TGTC_OK;
         TGTC_REQUIRE(rays_o && rays_d && rgb_fine && t_fine, "render_rays_plain: null pointer");
-        FusedArgs a{rays_o, rays_d, R, n_coarse, n_fine, near_, far_, jitter, coarse->dev, fine->dev, rgb_fine, t_fine};
+        FusedArgs a{rays_o, rays_d, R, n_coarse, n_fine, near_, far_, jitter, coarse->dev, fine->dev, rgb_fine, t_fine, nullptr};
         return launch_fused_render(coarse->precision, fine->precision, a, as_stream(stream));
     }
     return tgtc_render_rays_plain_chain(coarse, fine, rays_o, rays_d, R, n_coarse, n_fine, near_, far_, jitter, workspace,
@@ -132,7 +135,17 @@ extern "C" int tgtc_render_rays_styled(const tgtc_net* coarse, const tgtc_net* f
     TGTC_REQUIRE(workspace_bytes >= ws.total, "render_rays_styled: workspace of %zu bytes, need %zu", workspace_bytes,
                  ws.total);
     hipStream_t st = as_stream(stream);
-    int rc = tgtc_sample_coarse(rays_o, rays_d, R, n_coarse, near_, far_, jitter, nullptr, ws.ts_c, stream);
+    int rc;
+    if (!rgb_coarse && !t_coarse && coarse->kind == 0 && fused_depths_supports(coarse->precision, n_coarse, n_fine)) {
+        // no coarse image wanted: coarse depths -> coarse sigma -> weights -> fine depths never leave the ray kernel
+        FusedArgs a{rays_o, rays_d, R, n_coarse, n_fine, near_, far_, jitter, coarse->dev, coarse->dev, nullptr, nullptr, ws.ts_f};
+        rc = launch_fused_depths(coarse->precision, a, st);
+        if (rc) return rc;
+        rc = styled_forward_rays_impl(fine, style, rays_o, rays_d, ws.ts_f, z, R, n_coarse + n_fine, ws.rgb_f, ws.sigma_f, st);
+        if (rc) return rc;
+        return launch_composite(ws.rgb_f, ws.sigma_f, ws.ts_f, R, n_coarse + n_fine, rgb_fine, t_fine, nullptr, st);
+    }
+    rc = tgtc_sample_coarse(rays_o, rays_d, R, n_coarse, near_, far_, jitter, nullptr, ws.ts_c, stream);
     if (rc) return rc;
     float* rgb_c = rgb_coarse ? ws.rgb_c : nullptr;
     if (rgb_c)

@@ -39,8 +39,10 @@ struct FusedArgs {
     const char* net_f;    // fine handle
     float* rgb;           // [R, 3]
     float* t;             // [R]
+    float* ts_out;        // depths-only kernel (PF = kFusedDepthsOnly): [R, NC + NF] merged fine-pass depths, ascending
 };
 
+constexpr int kFusedDepthsOnly = -1;                      // PF of the kernel that stops after the fine sampling (stylised render)
 constexpr int kFusedMaxTotal = 256;                       // Nc + Nf supported by the per-wave LDS strip
 constexpr int kFusedStripBytes = (kFusedMaxTotal + 192 + 8) * 4;   // depths | weights / cdf (Nc <= 192) | compositing state
 
@@ -140,8 +142,9 @@ constexpr int kStripAll = 0, kStripW = kFusedMaxTotal, kStripAcc = kFusedMaxTota
 
 template <int PC, int PF>
 __global__ void __launch_bounds__(512, 2) fused_render_kernel(FusedArgs a) {
+    constexpr bool DEPTHS = PF == kFusedDepthsOnly;   // coarse passes + fine sampling only: the stylised fine pass follows in its own kernel
     using CC = typename FusedCfg<PC>::C;
-    using CF = typename FusedCfg<PF>::C;
+    using CF = typename FusedCfg<(DEPTHS ? PC : PF)>::C;
     static_assert(CC::NWAVES == 8 && CF::NWAVES == 8 && CC::SLOTS == CF::SLOTS, "one ring, eight waves");
     constexpr int NW = 8;
 
@@ -245,7 +248,7 @@ __global__ void __launch_bounds__(512, 2) fused_render_kernel(FusedArgs a) {
             wave_sync();
             depths(tt, tn);
             const bool last = tile + CC::NCT >= tiles_c;
-            fused_pass<PC, false>(smem, wave, lane, a.net_c, last ? a.net_f : a.net_c, o, d, tt, sig, col);
+            fused_pass<PC, false>(smem, wave, lane, a.net_c, (last && !DEPTHS) ? a.net_f : a.net_c, o, d, tt, sig, col);
             depths(tt, tn);   // recomputed rather than kept across the pass
             RayAccum acc = get_acc();
             float w[CC::NCT];
@@ -267,6 +270,12 @@ __global__ void __launch_bounds__(512, 2) fused_render_kernel(FusedArgs a) {
         }
         wave_sync();
         sample_fine_wave(strip() + kStripAll, strip() + kStripW, a.NC, a.NF);   // strip[0, NT) = merged depths, ascending
+        if constexpr (DEPTHS) {
+            wave_sync();
+            if (valid)
+                for (int i = fresh_lane(); i < NT; i += 64) a.ts_out[ray * NT + i] = strip()[kStripAll + i];
+            wave_sync();
+        } else {
         load_bias(a.net_f);
 
         // ---------------------------------------------------------------- fine passes (rgb, sigma) + compositing
@@ -300,6 +309,7 @@ __global__ void __launch_bounds__(512, 2) fused_render_kernel(FusedArgs a) {
             a.rgb[ray * 3 + 0] = acc.r, a.rgb[ray * 3 + 1] = acc.g, a.rgb[ray * 3 + 2] = acc.b;
             a.t[ray] = acc.t;
         }
+        }   // !DEPTHS
     }
     wait_vmcnt<0>();   // the look-ahead of the last pass must not outlive the workgroup's LDS
 }
@@ -320,6 +330,29 @@ int launch_fused_render(int prec_c, int prec_f, const FusedArgs& a, hipStream_t 
         return fail(TGTC_ERR_UNSUPPORTED, "fused render: no kernel for precisions %d (coarse) + %d (fine)", prec_c, prec_f);
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;
+}
+
+bool fused_render_supports(int prec_c, int prec_f, int n_coarse, int n_fine);
+
+// Coarse passes + fine sampling of the fused kernel alone: ts_out[R, NC + NF] = the merged depths the fine pass is evaluated
+// at (rendering.py:118-160 up to the second sample_pdf; the stylised fine pass then runs mlp_style.hip's kernel on them).
+int launch_fused_depths(int prec_c, const FusedArgs& a, hipStream_t st) {
+    int dev = 0, cus = 0;
+    TGTC_HIP_CHECK(hipGetDevice(&dev));
+    TGTC_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const long long groups = (a.R + 7) / 8;
+    const unsigned grid = (unsigned)(groups < cus ? groups : cus);
+    if (prec_c == TGTC_PREC_FP16X3)
+        fused_render_kernel<TGTC_PREC_FP16X3, kFusedDepthsOnly><<<grid, 512, 0, st>>>(a);
+    else if (prec_c == TGTC_PREC_FP16)
+        fused_render_kernel<TGTC_PREC_FP16, kFusedDepthsOnly><<<grid, 512, 0, st>>>(a);
+    else
+        return fail(TGTC_ERR_UNSUPPORTED, "fused depths: no kernel for coarse precision %d", prec_c);
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
+}
+bool fused_depths_supports(int prec_c, int n_coarse, int n_fine) {
+    return fused_render_supports(prec_c, prec_c, n_coarse, n_fine);
 }
 
 // can the fused kernel take this call?  (otherwise render.hip runs the chain of per-sample kernels)

@@ -80,7 +80,11 @@ class NerfTrainer:
     def backward(self, params, rgb, d_rgb, d_sigma):
         M = rgb.shape[0]
         ws = self.workspace(M, rgb.device)
-        grads = [torch.empty_like(p, dtype=torch.float32) for p in params]
+        flat = torch.empty(sum(p.numel() for p in params), device=rgb.device, dtype=torch.float32)     # back to back: one zero-fill
+        grads, at = [], 0
+        for p in params:
+            grads.append(flat[at:at + p.numel()].view(p.shape))
+            at += p.numel()
         hip.check(self.lib.tgtc_trainer_backward(self.handle, _table(params), hip.ptr(rgb), hip.ptr(d_rgb), hip.ptr(d_sigma), M,
                                                  hip.ptr(ws), ws.numel(), _table(grads), hip.stream()))
         return grads

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development timing: one Origin_train iteration (training.origin_train_step) on the unfused HIP dense layers,
+"""Development timing: one Origin_train iteration (training.origin_train_step) on the fused training kernels (TGTC_TRAIN_UNFUSED=1: the per-layer HIP dense layers),
 1024 rays x (64 coarse + 128 fine-pass samples)."""
 import os, sys, time
 import numpy as np, torch

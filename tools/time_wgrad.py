@@ -24,5 +24,5 @@ def timed(fn, n=5):
     ev[1].record(); torch.cuda.synchronize()
     return ev[0].elapsed_time(ev[1]) / n
 rgb, sigma = tr.forward(params, pts, dirs)
-print("M %d  ablate %s: forward %.3f ms  backward %.3f ms" % (M, os.environ.get("TGTC_WGRAD_ABLATE", "0"),
+print("M %d: forward %.3f ms  backward %.3f ms" % (M,
       timed(lambda: tr.forward(params, pts, dirs)), timed(lambda: tr.backward(params, rgb, g_rgb, g_sig))))
