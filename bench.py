@@ -283,8 +283,8 @@ def bench_train_step(steps, warmup, rays=1024):
         m.load_state_dict(t_state(synth.nerf_state(0))), mf.load_state_dict(t_state(synth.nerf_state(1)))
         m, mf = m.cuda().trainable(fused=fused), mf.cuda().trainable(fused=fused)
         opt = torch.optim.Adam(list(m.parameters()) + list(mf.parameters()), lr=5e-4)
-        ms, r = timed(lambda: training.origin_train_step(m, mf, opt, ro, rd, gt, 64, 64, 0., 1., sigma_noise_std=0.1))
-        assert np.isfinite(r["loss"])
+        ms, r = timed(lambda: training.origin_train_step(m, mf, opt, ro, rd, gt, 64, 64, 0., 1., sigma_noise_std=0.1, as_float=False))
+        assert np.isfinite(float(r["loss"]))
         return ms
 
     ms, ms_unfused = hip_iteration(True), hip_iteration(False)

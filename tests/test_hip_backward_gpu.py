@@ -153,17 +153,22 @@ def test_fused_training_path_matches_the_unfused_one():
                 m._trainer.status()
         a, b = grads[True], grads[False]
         assert float((a[0] - b[0]).abs().max()) <= 2e-5 and float((a[1] - b[1]).abs().max()) <= 2e-5 * float(b[1].abs().max())
-        for i, (ga, gb) in enumerate(zip(a[2], b[2])):
-            # The two forwards round differently at the 1e-7 level: among 4 097 x 2 432 ReLU units one or two pre-activations
-            # within rounding of zero gate differently.  Such a sample changes its own contribution to every layer below the
-            # flipped unit -- a RANK-ONE term dz[s] (x) h[s] per weight matrix, dense in the early layers.  So: the difference of
-            # the two gradients is at most eight rank-one terms (eight flipped samples; four seen at M = 4 097: singular values 3e-4 .. 9e-5, the fifth 1e-7) on top of 3e-5 of rounding, and small.
-            d, scale = (ga - gb).double(), float(gb.abs().max()) + 1e-30
-            assert float(d.abs().max()) <= 5e-3 * scale, (M, i, float(d.abs().max()) / scale)
-            if d.dim() == 2 and float(d.abs().max()) > 3e-5 * scale:
-                U, S, Vh = torch.linalg.svd(d, full_matrices=False)
-                d = d - (U[:, :8] * S[:8]) @ Vh[:8]
-                assert float(d.abs().max()) <= 3e-5 * scale, (M, i, float(d.abs().max()) / scale, S[:6].tolist())
+        # The two forwards round differently at the 1e-7 level: among 4 097 x 2 432 ReLU units a few pre-activations within
+        # rounding of zero gate differently.  Such a sample s changes its own pre-activation gradients in every layer below the
+        # flipped unit, i.e. it adds a RANK-ONE term d_dz[s] (x) h[s] to each weight gradient (dense in the early layers) and
+        # d_dz[s] to the bias gradient.  So per layer: dW_fused - dW_unfused is at most eight rank-one terms (eight flipped
+        # samples; four seen at M = 4 097: singular values 3e-4 .. 9e-5, the fifth 1e-7) on top of 3e-5 of rounding, the bias
+        # difference lies in the span of the same left singular vectors, and both are small (a sample is 1/sqrt(M) of a sum).
+        for l in range(12):
+            dW, db = (a[2][2 * l] - b[2][2 * l]).double(), (a[2][2 * l + 1] - b[2][2 * l + 1]).double()
+            sW, sb = float(b[2][2 * l].abs().max()) + 1e-30, float(b[2][2 * l + 1].abs().max()) + 1e-30
+            assert float(dW.abs().max()) <= 5e-2 * sW and float(db.abs().max()) <= 5e-2 * sb, (M, l)
+            U, S, Vh = torch.linalg.svd(dW, full_matrices=False)
+            r = min(8, S.numel())
+            dW = dW - (U[:, :r] * S[:r]) @ Vh[:r]
+            db = db - U[:, :r] @ (U[:, :r].T @ db)
+            assert float(dW.abs().max()) <= 3e-5 * sW, (M, l, "weight", float(dW.abs().max()) / sW, S[:10].tolist())
+            assert float(db.abs().max()) <= 3e-5 * sb, (M, l, "bias", float(db.abs().max()) / sb, S[:10].tolist())
 
 
 def test_style_mlp_gradients_match_the_oracle():

@@ -17,8 +17,11 @@ def img2mse(x, y):
 
 
 def origin_train_step(model, model_fine, optimizer, rays_o, rays_d, rgb_gt, N_samples, N_samples_fine, near, far,
-                      sigma_noise_std=1.0, jitter=None):
-    """-> dict(loss, loss_rgb, loss_rgb_fine) as Python floats; parameters of both networks updated in place."""
+                      sigma_noise_std=1.0, jitter=None, as_float=True):
+    """-> dict(loss, loss_rgb, loss_rgb_fine); parameters of both networks updated in place.  as_float=False returns the
+    losses as detached device scalars WITHOUT synchronising: the reference reads them only every i_print iterations
+    (train_tgtcs.py:257-266), and a float() per iteration serialises the host with the GPU."""
+    val = (lambda t: float(t.detach())) if as_float else (lambda t: t.detach())
     R = rays_o.shape[0]
     pts, ts = utils.sampling_pts_uniform(rays_o=rays_o, rays_d=rays_d, N_samples=N_samples, near=near, far=far, perturb=True,
                                          jitter=jitter)
@@ -33,11 +36,11 @@ def origin_train_step(model, model_fine, optimizer, rays_o, rays_d, rgb_gt, N_sa
         rgb_exp_fine, _, _ = utils.alpha_composition(ret['rgb'], ret['sigma'], ts_fine, sigma_noise_std)
         loss_rgb_fine = img2mse(rgb_gt, rgb_exp_fine)
         loss = loss + loss_rgb_fine
-        out['loss_rgb_fine'] = float(loss_rgb_fine.detach())
+        out['loss_rgb_fine'] = val(loss_rgb_fine)
     optimizer.zero_grad()
     loss.backward()
     optimizer.step()
-    out.update(loss=float(loss.detach()), loss_rgb=float(loss_rgb.detach()))
+    out.update(loss=val(loss), loss_rgb=val(loss_rgb))
     return out
 
 
@@ -91,7 +94,7 @@ class CoherenceState:
 def style_train_step(model, model_fine, concat_model, style_model, latents, optimizer, rays_o, rays_d, rgb_gt, style_ids,
                      frame_ids, N_samples, N_samples_fine, near, far, sigma_noise_std=1.0, rgb_loss_lambda=1.0,
                      logp_loss_lambda=0.0, data_type='llff', jitter=None, coherence=None, coh_batch=None,
-                     loss_coh_lambda=0.0):
+                     loss_coh_lambda=0.0, as_float=True):
     """One `Style_train` iteration (train_tgtcs.py:352-482): the shuffled batch's rendering, pixel and -log p terms and,
     with `coherence` (a CoherenceState) and `coh_batch` (dict rays_o, rays_d, rgb_origin, style_id, frame_id [, jitter]: the
     frame-ordered batch of `loss_coh_get_batch`, :366-370), the cosine-coherence term between consecutive frame-ordered
@@ -140,7 +143,8 @@ def style_train_step(model, model_fine, concat_model, style_model, latents, opti
     optimizer.zero_grad()
     total.backward()
     optimizer.step()
-    out = {'loss': float(loss.detach()), 'loss_rgb': float(loss_rgb.detach()), 'loss_logp': float(loss_logp.detach())}
+    val = (lambda t: float(t.detach())) if as_float else (lambda t: t.detach())     # see origin_train_step
+    out = {'loss': val(loss), 'loss_rgb': val(loss_rgb), 'loss_logp': val(loss_logp)}
     if loss_coh is not None:
-        out['loss_coh'] = float(loss_coh.detach())
+        out['loss_coh'] = val(loss_coh)
     return out

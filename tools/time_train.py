@@ -19,8 +19,10 @@ opt = torch.optim.Adam(list(m.parameters()) + list(mf.parameters()), lr=5e-4)
 for i in range(13):
     if i == 3:
         torch.cuda.synchronize(); t0 = time.time()
-    r = training.origin_train_step(m, mf, opt, ro, rd, gt, 64, 64, 0., 1., sigma_noise_std=0.1)
+    r = training.origin_train_step(m, mf, opt, ro, rd, gt, 64, 64, 0., 1., sigma_noise_std=0.1, as_float=False)
+t_cpu = (time.time() - t0) / 10          # host time to ENQUEUE an iteration (the losses come back as device scalars, unread)
 torch.cuda.synchronize()
 dt = (time.time() - t0) / 10
 samples = R * (64 + 128)
-print(("fused " if FUSED else "unfused ") + "origin_train_step: %d rays, %d network samples: %.1f ms per iteration (%.2f M samples/s), loss %.4f" % (R, samples, dt * 1e3, samples / dt / 1e6, r["loss"]))
+print("host enqueue time per iteration %.2f ms" % (t_cpu * 1e3))
+print(("fused " if FUSED else "unfused ") + "origin_train_step: %d rays, %d network samples: %.1f ms per iteration (%.2f M samples/s), loss %.4f" % (R, samples, dt * 1e3, samples / dt / 1e6, float(r["loss"])))
