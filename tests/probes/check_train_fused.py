@@ -48,6 +48,29 @@ params = [p.detach().float().contiguous() for p in fused_train.mlp_parameters(ne
 rgb, sigma = tr.forward(params, pts.cuda(), dirs.cuda())
 torch.cuda.synchronize()
 
+ws = tr.workspace(M, torch.device("cuda"))
+m_pad = (M + 127) // 128 * 128
+hi = ws[:m_pad * H_COLS * 2].view(torch.float16).float().cpu()
+lo_off = (m_pad * H_COLS * 2 + 255) // 256 * 256
+lo = ws[lo_off:lo_off + m_pad * H_COLS * 2].view(torch.float16).float().cpu()
+flat = hi.double() + lo.double()
+seg = lambda buf, col0, width: buf[col0 * m_pad: col0 * m_pad + m_pad * width].reshape(m_pad, width)[:M]     # segment-major planes
+p256, p128 = act_perm(256), act_perm(128)
+
+def unperm(buf, col0, width, perm):
+    got = torch.zeros(M, width, dtype=torch.float64)
+    got[:, perm] = seg(buf, col0, width)
+    return got
+
+
+# The reference backward uses the HIP forward's ReLU gates (stash > 0): with M x 2 432 units a few pre-activations sit within
+# rounding of zero and gate differently in float64, which changes that sample's whole gradient (seen at M = 131 072: a dozen
+# samples, max-norm error 0.3) -- a property of the comparison, not of the kernels.  The forward check below still compares
+# the stashed activations with relu(z) of the float64 reference.
+gate = [unperm(flat, h_layer(l), 256, p256) > 0 for l in range(8)]
+gate_remap, gate_f = unperm(flat, H_REMAP, 256, p256) > 0, unperm(flat, H_F, 128, p128) > 0
+flips = 0
+
 # ---- float64 reference with the intermediate activations kept
 w = {k: v.clone().requires_grad_() for k, v in T(sd, torch.float64).items()}
 pe = fields.posenc(pts, 10).to(torch.float32).double()
@@ -61,37 +84,28 @@ for i in range(8):
     z = lin("base_layers.%d" % i, h)
     z.retain_grad()
     zs.append(z)
-    h = torch.relu(z)
-    hs.append(h)
+    flips += int(((z > 0) != gate[i]).sum())
+    h = z * gate[i]
+    hs.append(torch.relu(z))
 sig_ref = lin("sigma_layer", h).squeeze(-1)
 z_remap = lin("base_remap_layer", h)
 z_remap.retain_grad()
-remap = torch.relu(z_remap)
+flips += int(((z_remap > 0) != gate_remap).sum())
+remap = z_remap * gate_remap
 z_f = lin("rgb_layers.0", torch.cat([remap, de], -1))
 z_f.retain_grad()
-f = torch.relu(z_f)
+flips += int(((z_f > 0) != gate_f).sum())
+f = z_f * gate_f
 z_rgb = lin("rgb_layers.1", f)
 z_rgb.retain_grad()
 rgb_ref = torch.sigmoid(z_rgb)
 rel = lambda a, b: float((a.double().cpu() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-30))
-print("forward: rgb rel %.2e  sigma rel %.2e" % (rel(rgb, rgb_ref), rel(sigma, sig_ref)))
+print("forward: rgb rel %.2e  sigma rel %.2e   (%d ReLU units gate differently in float64)" % (rel(rgb, rgb_ref), rel(sigma, sig_ref), flips))
 
-ws = tr.workspace(M, torch.device("cuda"))
-m_pad = (M + 127) // 128 * 128
-hi = ws[:m_pad * H_COLS * 2].view(torch.float16).float().cpu()
-lo_off = (m_pad * H_COLS * 2 + 255) // 256 * 256
-lo = ws[lo_off:lo_off + m_pad * H_COLS * 2].view(torch.float16).float().cpu()
-flat = hi.double() + lo.double()
-seg = lambda buf, col0, width: buf[col0 * m_pad: col0 * m_pad + m_pad * width].reshape(m_pad, width)[:M]     # segment-major planes
-p256, p128 = act_perm(256), act_perm(128)
 for l in range(8):
-    got = torch.zeros(M, 256, dtype=torch.float64)
-    got[:, p256] = seg(flat, h_layer(l), 256)
-    print("  stash h%d rel %.2e" % (l, rel(got, hs[l])))
-got = torch.zeros(M, 256, dtype=torch.float64); got[:, p256] = seg(flat, H_REMAP, 256)
-print("  stash remap rel %.2e" % rel(got, remap))
-got = torch.zeros(M, 128, dtype=torch.float64); got[:, p128] = seg(flat, H_F, 128)
-print("  stash f rel %.2e" % rel(got, f))
+    print("  stash h%d rel %.2e" % (l, rel(unperm(flat, h_layer(l), 256, p256), hs[l])))
+print("  stash remap rel %.2e" % rel(unperm(flat, H_REMAP, 256, p256), torch.relu(z_remap)))
+print("  stash f rel %.2e" % rel(unperm(flat, H_F, 128, p128), torch.relu(z_f)))
 
 # ---- backward
 (rgb_ref * g_rgb.double()).sum().backward(retain_graph=True)
