@@ -175,12 +175,22 @@ int tgtc_style_mlp_forward(const tgtc_net* style, const float* x, const float* c
  * latent z [R,32], style MLP on mean(z) broadcast.  Outputs rgb [R,N,3], sigma [R,N]. */
 int tgtc_styled_forward_rays(const tgtc_net* nerf, const tgtc_net* style, const double* rays_o, const double* rays_d,
                              const float* ts, const float* z, int64_t R, int N, float* rgb, float* sigma, void* stream);
-/* The render_style chain (rendering.py:118-178). */
+/* The stylised render of rays (rendering.py:109-182 render_style): like tgtc_render_rays_plain with the stylised colour
+ * (per-ray latent z float [R,32]).  tgtc_render_rays_styled runs it as ONE persistent kernel (a wavefront owns a ray; coarse
+ * passes, fine sampling, concat MLP + NeRF trunk + style MLP per fine tile and compositing back to back; no per-sample
+ * tensor, `workspace` not touched and may be NULL) whenever the three handles are TGTC_PREC_FP16X3, the sample counts
+ * satisfy the rule of tgtc_render_rays_plain and the coarse image is not requested; otherwise it falls back to
+ * tgtc_render_rays_styled_chain, the same arithmetic as a sequence of per-sample kernels through `workspace`. */
 int tgtc_render_rays_styled(const tgtc_net* coarse, const tgtc_net* fine, const tgtc_net* style,
                             const double* rays_o, const double* rays_d, const float* z, int64_t R, int n_coarse,
                             int n_fine, float near_, float far_, const float* jitter, void* workspace,
                             size_t workspace_bytes, float* rgb_fine, float* t_fine, float* rgb_coarse,
                             float* t_coarse, void* stream);
+int tgtc_render_rays_styled_chain(const tgtc_net* coarse, const tgtc_net* fine, const tgtc_net* style,
+                                  const double* rays_o, const double* rays_d, const float* z, int64_t R, int n_coarse,
+                                  int n_fine, float near_, float far_, const float* jitter, void* workspace,
+                                  size_t workspace_bytes, float* rgb_fine, float* t_fine, float* rgb_coarse,
+                                  float* t_coarse, void* stream);
 
 #ifdef __cplusplus
 }

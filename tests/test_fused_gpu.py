@@ -96,3 +96,45 @@ def test_fused_falls_back_to_the_chain():
     assert torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["t"], b["t"])
     c = r.render(ro, rd, 128, 64, want_coarse=True)
     assert "rgb_coarse" in c and bool(torch.isfinite(c["rgb_coarse"]).all())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The stylised ray kernel behind tgtc_render_rays_styled (render_styled_fused.hip)
+def styled_renderer(fused):
+    from tgtc_style_amd import models, rendering
+    nets = []
+    for seed, mode in ((0, "coarse"), (1, "fine")):
+        m = models.StyleNerf(Args, mode=mode)
+        m.load_state_dict(T(synth.nerf_state(seed)))
+        nets.append(m.cuda())
+    cm, sm = models.StyleMLP_before_concat(type("A", (Args,), {"style_D": 8, "vae_latent": 32})), \
+        models.StyleMLP_Wild_multilayers(type("A", (Args,), {"style_D": 8, "vae_latent": 32}))
+    cm.load_state_dict(T(synth.concat_state(2))), sm.load_state_dict(T(synth.style_state(3)))
+    return rendering.RayRenderer(nets[0], nets[1], style=models.StylePair(cm.cuda(), sm.cuda()), fused=fused)
+
+
+@pytest.mark.parametrize("nc,nf", [(128, 64), (64, 64), (16, 16)])
+def test_fused_styled_render_against_the_chain(nc, nf):
+    """One launch of the stylised ray kernel against the chain of per-sample kernels (tgtc_render_rays_styled_chain: same
+    network arithmetic, compositing scan associated differently), with and without jitter, ragged ray counts; the chain
+    itself is pinned to the reference's own stylised renders (tests/test_hip_style.py, g8)."""
+    from tgtc_style_amd import utils
+    H = W = 400
+    R = 1003
+    ro, rd = utils.gen_rays(H, W, synth.fern_intrinsics(H, W), synth.spiral_pose(2), first_pixel=201 * W + 17, n=R)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    z = torch.randn(R, 32, device="cuda", generator=gen)
+    fused, chain = styled_renderer(True), styled_renderer(False)
+    assert fused._fused_styled_shape(nc, nf)
+    for jit in (None, torch.rand(R, nc, device="cuda", generator=gen)):
+        a = fused.render(ro, rd, nc, nf, near=0., far=1., jitter=jit, z=z)
+        b = chain.render(ro, rd, nc, nf, near=0., far=1., jitter=jit, z=z)
+        assert bool(torch.isfinite(a["rgb"]).all()) and bool(torch.isfinite(a["t"]).all())
+        e = max(float((a["rgb"] - b["rgb"]).abs().max()), float((a["t"] - b["t"]).abs().max()))
+        print("styled %dc+%df jitter %s: fused vs chain %.2e" % (nc, nf, jit is not None, e))
+        assert e <= VS_CHAIN["fp16x3"]
+    # re-sharding: a ray's bits do not depend on the launch that renders it
+    whole = fused.render(ro, rd, nc, nf, z=z)
+    for lo, hi in ((0, 1), (5, 18), (500, 1003)):
+        part = fused.render(ro[lo:hi].contiguous(), rd[lo:hi].contiguous(), nc, nf, z=z[lo:hi].contiguous())
+        assert torch.equal(part["rgb"], whole["rgb"][lo:hi]) and torch.equal(part["t"], whole["t"][lo:hi]), (lo, hi)

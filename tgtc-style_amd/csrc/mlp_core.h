@@ -180,7 +180,8 @@ struct WeightStream {
     static constexpr int STAG = PERSIST ? TGTC_STAGGER : 0;           // register groups by which waves 4..7 run behind
     static constexpr int LOOK = C::SLOTS - 1 - (STAG > 0 ? 1 : 0);    // PERSIST: chunks issued ahead of the one being entered
     bool late = false;                                                 // wave-uniform: wave >= 4 (STAG > 0 only)
-    static_assert(!PERSIST || Map::NSEG == 1, "persistent streams are single segment");
+    // (a persistent stream of several segments -- the stylised ray kernel's concat | NeRF trunk | style -- re-enters its own
+    // first segment or hands over to another stream through `next`; its dummy chunks are the bytes behind the LAST segment)
     // LDS -> register staging in bursts of G fragments, double buffered: group g+1 is read while the
     // MFMAs of group g run.  (hipcc only ever emits `s_waitcnt lgkmcnt(0)` here, never a counted wait,
     // so each wait must find every outstanding read already old: one burst per group, issued right
@@ -262,7 +263,7 @@ struct WeightStream {
         static_assert(PERSIST, "enter_ring() belongs to persistent streams");
         wait_vmcnt<(LOOK - 2) * C::GPC>();
         __builtin_amdgcn_s_barrier();
-        src[0] = next;
+        if constexpr (Map::NSEG == 1) src[0] = next;
         issue<LOOK>();
     }
     __device__ __forceinline__ void enter() {

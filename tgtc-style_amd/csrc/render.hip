@@ -5,26 +5,9 @@
 #include "common.h"
 
 #include "mlp_pack.h"
+#include "render_args.h"
 
 namespace tgtc {
-struct FusedArgs {   // render_fused.hip
-    const double* rays_o;
-    const double* rays_d;
-    long long R;
-    int NC, NF;
-    float near_, far_;
-    const float* jitter;
-    const char* net_c;
-    const char* net_f;
-    float* rgb;
-    float* t;
-    float* ts_out;
-};
-int launch_fused_render(int prec_c, int prec_f, const FusedArgs& a, hipStream_t st);
-int launch_fused_depths(int prec_c, const FusedArgs& a, hipStream_t st);
-bool fused_depths_supports(int prec_c, int n_coarse, int n_fine);
-bool fused_render_supports(int prec_c, int prec_f, int n_coarse, int n_fine);
-
 int launch_composite(const float* rgb, const float* sigma, const float* ts, int64_t R, int N, float* rgb_exp,
                      float* t_exp, float* weights, hipStream_t st);
 int launch_sample_fine(const double* rays_o, const double* rays_d, const float* ts, const float* weights, int64_t R,
@@ -118,14 +101,37 @@ extern "C" int tgtc_render_rays_plain_chain(const tgtc_net* coarse, const tgtc_n
     return launch_composite(ws.rgb_f, ws.sigma_f, ws.ts_f, R, n_coarse + n_fine, rgb_fine, t_fine, nullptr, st);
 }
 
-// rendering.py:118-178 (render_style): like the plain chain, with the stylised colour on both passes.
-// The coarse colours only matter if the caller asks for the coarse image: the fine sampler consumes the
-// weights, which depend on sigma alone, so by default the coarse pass runs the sigma-only NeRF kernel.
+// rendering.py:118-178 (render_style).  Whenever the sample counts and precisions allow it (fp16x3 everywhere) and the caller
+// does not ask for the coarse image this is ONE launch of the stylised ray kernel (render_styled_fused.hip) and the workspace is
+// not touched; otherwise the chain of per-sample kernels below runs (tgtc_render_rays_styled_chain, always available).
 extern "C" int tgtc_render_rays_styled(const tgtc_net* coarse, const tgtc_net* fine, const tgtc_net* style,
                                        const double* rays_o, const double* rays_d, const float* z, int64_t R,
                                        int n_coarse, int n_fine, float near_, float far_, const float* jitter,
                                        void* workspace, size_t workspace_bytes, float* rgb_fine, float* t_fine,
                                        float* rgb_coarse, float* t_coarse, void* stream) {
+    TGTC_REQUIRE(coarse && fine && style && R >= 0, "render_rays_styled: bad argument");
+    if (!rgb_coarse && !t_coarse && coarse->kind == 0 && fine->kind == 0 && style->kind == 1 &&
+        fused_styled_supports(coarse->precision, fine->precision, style->precision, n_coarse, n_fine)) {
+        if (R == 0) return TGTC_OK;
+        TGTC_REQUIRE(rays_o && rays_d && z && rgb_fine && t_fine, "render_rays_styled: null pointer");
+        FusedStyledArgs a{};
+        a.ray = FusedArgs{rays_o, rays_d, R, n_coarse, n_fine, near_, far_, jitter, coarse->dev, fine->dev, rgb_fine, t_fine, nullptr};
+        a.z = z, a.pair_bias = style->dev, a.concat_stream = style->dev + style->bias_bytes;
+        a.style_stream = style->dev + style->stream2_off, a.slab = style->dev + style->stash_off;
+        return launch_fused_styled(coarse->precision, a, style->n_wg, as_stream(stream));
+    }
+    return tgtc_render_rays_styled_chain(coarse, fine, style, rays_o, rays_d, z, R, n_coarse, n_fine, near_, far_, jitter, workspace,
+                                         workspace_bytes, rgb_fine, t_fine, rgb_coarse, t_coarse, stream);
+}
+
+// The stylised chain of per-sample kernels: like the plain chain, with the stylised colour on both passes.
+// The coarse colours only matter if the caller asks for the coarse image: the fine sampler consumes the
+// weights, which depend on sigma alone, so by default the coarse pass runs the sigma-only NeRF kernel.
+extern "C" int tgtc_render_rays_styled_chain(const tgtc_net* coarse, const tgtc_net* fine, const tgtc_net* style,
+                                             const double* rays_o, const double* rays_d, const float* z, int64_t R,
+                                             int n_coarse, int n_fine, float near_, float far_, const float* jitter,
+                                             void* workspace, size_t workspace_bytes, float* rgb_fine, float* t_fine,
+                                             float* rgb_coarse, float* t_coarse, void* stream) {
     TGTC_REQUIRE(coarse && fine && style && R >= 0, "render_rays_styled: bad argument");
     TGTC_REQUIRE(n_coarse >= 3 && n_fine >= 1, "render_rays_styled: need n_coarse >= 3 and n_fine >= 1 (got %d, %d)",
                  n_coarse, n_fine);

@@ -14,131 +14,9 @@
 //
 // Per-tile arithmetic is the code of the per-sample kernels (mlp_nerf_chain.h, mlp_nerf_mx_chain.h,
 // raymarch_dev.h), so the result of a ray does not depend on which wave, workgroup or launch renders it.
-#include "common.h"
-#include "mlp_core.h"
-#ifndef TGTC_FUSED_X3_ASM_DMA
-#define TGTC_FUSED_X3_ASM_DMA false   // fp16 / fp16x3 passes: builtin LDS-DMA (asm + SGPR-base addressing measured, profiles section 16)
-#endif
-#include "mlp_layouts.h"
-#include "mlp_mx.h"
-#include "mlp_nerf_chain.h"
-#include "mlp_nerf_mx_chain.h"
-#include "mlp_pack.h"
-#include "raymarch_dev.h"
+#include "render_fused.h"
 
 namespace tgtc {
-
-struct FusedArgs {
-    const double* rays_o;
-    const double* rays_d;
-    long long R;
-    int NC, NF;
-    float near_, far_;
-    const float* jitter;  // [R, NC] stratified-jitter uniforms, or null (utils.py:518-524)
-    const char* net_c;    // coarse handle: bias region (kNerfBiasBytes) followed by the packed stream
-    const char* net_f;    // fine handle
-    float* rgb;           // [R, 3]
-    float* t;             // [R]
-    float* ts_out;        // depths-only kernel (PF = kFusedDepthsOnly): [R, NC + NF] merged fine-pass depths, ascending
-};
-
-constexpr int kFusedDepthsOnly = -1;                      // PF of the kernel that stops after the fine sampling (stylised render)
-constexpr int kFusedMaxTotal = 256;                       // Nc + Nf supported by the per-wave LDS strip
-constexpr int kFusedStripBytes = (kFusedMaxTotal + 192 + 8) * 4;   // depths | weights / cdf (Nc <= 192) | compositing state
-
-// Geometry per precision: 8 waves = 2 per SIMD (mlp_nerf.hip CfgFast / CfgExact, mlp_nerf_mx.hip CfgMx)
-template <int PREC>
-struct FusedCfg;
-template <>
-struct FusedCfg<TGTC_PREC_FP16X3> {
-    using C = MlpCfg<8, 1, true, 4>;
-};
-template <>
-struct FusedCfg<TGTC_PREC_FP16> {
-    using C = MlpCfg<8, 2, false, 4>;
-};
-template <>
-struct FusedCfg<TGTC_PREC_FP16_FP6> {
-    using C = MlpCfg<8, 1, false, 4>;
-};
-
-template <int PREC, bool FULL>
-struct FusedStream {
-    using C = typename FusedCfg<PREC>::C;
-    using type = WeightStream<C, SingleStreamMap<(FULL ? NerfLayout::kFragsFull : NerfLayout::kFragsSigma)>, true, TGTC_FUSED_X3_ASM_DMA>;
-};
-template <bool FULL>
-struct FusedStream<TGTC_PREC_FP16_FP6, FULL> {
-    using C = typename FusedCfg<TGTC_PREC_FP16_FP6>::C;
-    using type = MxReader<C, SingleStreamMap<nerf_mx_units(FULL)>, kNerfMxTable, true>;
-};
-
-__device__ __forceinline__ double uniform_f64(double x) {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-
-// One pass: the network of one precision over this wave's NCT tiles (depths tt[c]) of its ray (o, d).
-// sig[c] / col[c][0..2] are valid in lanes 0..15 (sample = lane & 15).  Everything per-lane the pass needs (stream
-// reader, LDS bases) is rebuilt here from the wave / lane ids, so that nothing but scalars lives across the ~250
-// registers of the layer chain (values that do are spilled to scratch, and a scratch reload waits vmcnt(0), i.e. for
-// the whole look-ahead of the ring).
-template <int PREC, bool FULL>
-__device__ __forceinline__ void fused_pass(char* smem, int wave, int lane, const char* cur_net, const char* next_net,
-                                           const double (&o)[3], const double (&d)[3],
-                                           const float (&tt)[FusedCfg<PREC>::C::NCT], float (&sig)[FusedCfg<PREC>::C::NCT],
-                                           float (&col)[FusedCfg<PREC>::C::NCT][3]) {
-    using C = typename FusedCfg<PREC>::C;
-    using StreamT = typename FusedStream<PREC, FULL>::type;
-    constexpr int NCT = C::NCT;
-    constexpr bool SPLIT = PREC != TGTC_PREC_FP16;   // hi + lo encodings (fp16x3 and the fp16+fp6 PE k-steps)
-    const int g = lane >> 4, n = lane & 15;
-    half8 pe_h[2][NCT], pe_l[2][NCT];
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) {
-        double p[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p[k] = o[k] + (double)tt[c] * d[k];   // rendering.py:27 / utils.py:529,578
-        half8 h2[2], l2[2];
-        encode_point<SPLIT, SPLIT>(p, g, h2, l2, nullptr);
-        pe_h[0][c] = h2[0], pe_h[1][c] = h2[1], pe_l[0][c] = l2[0], pe_l[1][c] = l2[1];
-    }
-    auto colour = [&](auto c_, auto h_, const float4v& acc) {
-        constexpr int c = decltype(c_)::value, hf = decltype(h_)::value;
-#pragma unroll
-        for (int r = 2 * hf; r < (hf ? 3 : 2); ++r) col[c][r] = 1.0f / (1.0f + expf(-acc[r]));   // models.py:111
-    };
-    const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * g);
-    StreamT st;
-    const char* const one[1] = {cur_net + kNerfBiasBytes};
-    st.init(one, smem, wave, lane);
-    const char* const next_src = StreamT::lane_src(next_net + kNerfBiasBytes, wave, lane);
-    if constexpr (PREC == TGTC_PREC_FP16_FP6) {
-        constexpr int NQ = nerf_mx_groups(FULL);
-        const lds_cptr rs_lane = opaque((lds_cptr)smem + C::RING_BYTES + kNerfMxScaleOff + 2 * n);
-        st.ring.next = st.ring.src[0];   // the stream this pass enters (its first chunks are in flight) ...
-        st.template enter<0, NQ>();
-        st.ring.next = next_src;         // ... and the one its look-ahead runs into
-        const half8 Ph[2] = {pe_h[0][0], pe_h[1][0]}, Pl[2] = {pe_l[0][0], pe_l[1][0]};
-        nerf_chain_mx<C, FULL>(
-            st, bias_lane, rs_lane, Ph, Pl, [&](half8& dh, half8& dl) { encode_dir<true, true>(d, g, dh, dl, nullptr); },
-            [&](float s) { sig[0] = s; }, [](auto, auto, const float4v&) {},
-            [&](auto h_, const float4v& acc) { colour(ic<0>{}, h_, acc); });
-        st.template finish<NQ>();
-    } else {
-        st.next = st.src[0];
-        st.enter();
-        st.next = next_src;
-        nerf_chain<C, FULL>(
-            st, bias_lane, pe_h, pe_l, [&](auto, half8& dh, half8& dl) { encode_dir<SPLIT, SPLIT>(d, g, dh, dl, nullptr); },
-            [&](auto c_, float s) { sig[decltype(c_)::value] = s; }, [](auto, auto, auto, const float4v&) {}, colour);
-        st.template finish<StreamT::NCHUNK>();
-    }
-}
-
-// per-wave LDS strip: depths | weights / cdf | compositing state
-constexpr int kStripAll = 0, kStripW = kFusedMaxTotal, kStripAcc = kFusedMaxTotal + 192;
 
 template <int PC, int PF>
 __global__ void __launch_bounds__(512, 2) fused_render_kernel(FusedArgs a) {
@@ -248,7 +126,7 @@ __global__ void __launch_bounds__(512, 2) fused_render_kernel(FusedArgs a) {
             wave_sync();
             depths(tt, tn);
             const bool last = tile + CC::NCT >= tiles_c;
-            fused_pass<PC, false>(smem, wave, lane, a.net_c, (last && !DEPTHS) ? a.net_f : a.net_c, o, d, tt, sig, col);
+            fused_pass<PC, false>(smem, wave, lane, a.net_c, ((last && !DEPTHS) ? a.net_f : a.net_c) + kNerfBiasBytes, o, d, tt, sig, col);
             depths(tt, tn);   // recomputed rather than kept across the pass
             RayAccum acc = get_acc();
             float w[CC::NCT];
@@ -293,7 +171,7 @@ __global__ void __launch_bounds__(512, 2) fused_render_kernel(FusedArgs a) {
             float tt[CF::NCT], tn[CF::NCT], sig[CF::NCT], col[CF::NCT][3];
             depths(tt, tn);
             const bool last = tile + CF::NCT >= tiles_f;
-            fused_pass<PF, true>(smem, wave, lane, a.net_f, last ? a.net_c : a.net_f, o, d, tt, sig, col);
+            fused_pass<PF, true>(smem, wave, lane, a.net_f, (last ? a.net_c : a.net_f) + kNerfBiasBytes, o, d, tt, sig, col);
             depths(tt, tn);
             RayAccum acc = get_acc();
             const int n = fresh_lane() & 15;
@@ -331,8 +209,6 @@ int launch_fused_render(int prec_c, int prec_f, const FusedArgs& a, hipStream_t 
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;
 }
-
-bool fused_render_supports(int prec_c, int prec_f, int n_coarse, int n_fine);
 
 // Coarse passes + fine sampling of the fused kernel alone: ts_out[R, NC + NF] = the merged depths the fine pass is evaluated
 // at (rendering.py:118-160 up to the second sample_pdf; the stylised fine pass then runs mlp_style.hip's kernel on them).

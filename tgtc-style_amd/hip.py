@@ -70,6 +70,9 @@ _OPTIONAL = {
     "tgtc_render_rays_styled": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                 c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p],
+    "tgtc_render_rays_styled_chain": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                      c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p],
 }
 
 

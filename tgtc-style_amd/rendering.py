@@ -23,8 +23,9 @@ class RayRenderer:
     """
 
     def __init__(self, coarse, fine, style=None, fused=True):
-        """fused=False forces the chain of per-sample kernels (tgtc_render_rays_plain_chain) where the library
-        would otherwise run the single persistent ray kernel; results agree to rounding (tests/test_fused_gpu.py)."""
+        """fused=False forces the chain of per-sample kernels (tgtc_render_rays_plain_chain / tgtc_render_rays_styled_chain)
+        where the library would otherwise run a single persistent ray kernel; results agree to rounding
+        (tests/test_fused_gpu.py)."""
         self.coarse, self.fine, self.style, self.fused = coarse, fine, style, fused
         self._ws = None
 
@@ -35,6 +36,11 @@ class RayRenderer:
         pair = (pc, pf) in (("fp16x3", "fp16x3"), ("fp16x3", "fp16mx"), ("fp16", "fp16"))
         step = 32 if pc == "fp16" else 16
         return pair and nf >= 1 and nc >= 16 and nc % step == 0 and (nc + nf) % step == 0 and nc <= 192 and nc + nf <= 256
+
+    def _fused_styled_shape(self, nc, nf):
+        """The same for tgtc_render_rays_styled: the stylised ray kernel is built for fp16x3 in all three handles."""
+        precs = {self.coarse.packed().precision, self.fine.packed().precision, self.style.packed().precision}
+        return precs == {"fp16x3"} and self._fused_shape(nc, nf)
 
     def _workspace(self, R, nc, nf, device):
         need = hip.load().tgtc_render_workspace_bytes(R, nc, nf)
@@ -52,7 +58,8 @@ class RayRenderer:
         rays_d = rays_d.to(torch.float64).contiguous()
         R, dev = rays_o.shape[0], rays_o.device
         plain = self.style is None or z is None
-        one_kernel = plain and self.fused and not want_coarse and self._fused_shape(n_coarse, n_fine)
+        one_kernel = self.fused and not want_coarse and (self._fused_shape(n_coarse, n_fine) if plain else
+                                                         self._fused_styled_shape(n_coarse, n_fine))
         ws = None if one_kernel else self._workspace(R, n_coarse, n_fine, dev)
         rgb = torch.empty(R, 3, device=dev, dtype=torch.float32)
         t = torch.empty(R, device=dev, dtype=torch.float32)
@@ -68,11 +75,10 @@ class RayRenderer:
                          hip.stream()))
         else:
             z = z.to(torch.float32).contiguous()
-            hip.check(lib.tgtc_render_rays_styled(self.coarse.packed().handle, self.fine.packed().handle,
-                                                  self.style.packed().handle, hip.ptr(rays_o), hip.ptr(rays_d),
-                                                  hip.ptr(z), R, n_coarse, n_fine, float(near), float(far),
-                                                  hip.ptr(jitter), hip.ptr(ws), ws.numel(), hip.ptr(rgb), hip.ptr(t),
-                                                  hip.ptr(rgb_c), hip.ptr(t_c), hip.stream()))
+            fn = lib.tgtc_render_rays_styled if self.fused else lib.tgtc_render_rays_styled_chain
+            hip.check(fn(self.coarse.packed().handle, self.fine.packed().handle, self.style.packed().handle, hip.ptr(rays_o),
+                         hip.ptr(rays_d), hip.ptr(z), R, n_coarse, n_fine, float(near), float(far), hip.ptr(jitter), hip.ptr(ws),
+                         0 if ws is None else ws.numel(), hip.ptr(rgb), hip.ptr(t), hip.ptr(rgb_c), hip.ptr(t_c), hip.stream()))
         out = {"rgb": rgb, "t": t}
         if want_coarse:
             out["rgb_coarse"], out["t_coarse"] = rgb_c, t_c
