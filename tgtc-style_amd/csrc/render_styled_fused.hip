@@ -26,11 +26,11 @@ constexpr int kStyledSlots = kRingSlots - 1;
 constexpr int kStripZ = kStripAcc + 8;                                  // 32 floats of latent behind the compositing state
 constexpr int kStyledStripBytes = kFusedStripBytes + 32 * 4;
 
-// One stylised pass over this wave's tile (depth tt) of its ray: sig / col valid in lanes 0..15.
+// One stylised pass over this wave's tile (depth tt) of its ray: *sig_slot (this lane's word of the strip) / col valid in lanes 0..15.
 template <class C>
 __device__ __forceinline__ void styled_pass(char* smem, int wave, int lane, const FusedStyledArgs& a, const char* next_stream,
                                             const double (&o)[3], const double (&d)[3], float tt, const float* z32, char* lane_slab,
-                                            float& sig, float (&col)[3]) {
+                                            float* sig_slot, float (&col)[3]) {
     static_assert(C::NCT == 1 && C::SPLIT, "the stylised ray kernel is built for fp16x3 (one column tile per wave)");
     using Map = StyledMap<C>;
     using L = NerfLayout;
@@ -95,7 +95,9 @@ __device__ __forceinline__ void styled_pass(char* smem, int wave, int lane, cons
     dense_layer<C, FN + L::frag0(6), 8, 16, L::bias0(6)>(ws, nerf_bias, Xh, Xl, to_Y);
     dense_layer<C, FN + L::frag0(7), 8, 16, L::bias0(7)>(ws, nerf_bias, Yh, Yl, to_X);
     dense_layer<C, FN + L::frag0(8), 8, 1, L::bias0(8)>(ws, nerf_bias, Xh, Xl, [&](auto, auto, auto h_, const float4v& acc) {
-        if constexpr (decltype(h_)::value == 0) sig = acc[0];                           // models.py:103
+        // models.py:103.  sigma waits for the colour in the wave's strip, not in a register: it would live through the 1 200
+        // fragments of the style MLP, and the compiler spills the whole accumulator tile for it (a scratch store in the loop)
+        if constexpr (decltype(h_)::value == 0) *sig_slot = acc[0];
     });
     dense_layer<C, FN + L::frag0(9), 8, 16, L::bias0(9)>(ws, nerf_bias, Xh, Xl, to_Y);  // base_remap -> Y
     ws.template skip<FN + kTrunkFrags, Map::GAP>();
@@ -191,7 +193,9 @@ __global__ void __launch_bounds__(512, 2) fused_styled_kernel(FusedStyledArgs sa
         first.next = first.src[0];
         first.persist_prologue();
     }
-    char* const lane_slab = sa.slab + (size_t)blockIdx.x * kStashBytesPerWG + (size_t)threadIdx.x * 16;
+    // this lane's 16-byte column of the workgroup's slab, re-derived per pass (a 64-bit per-lane pointer kept across the
+    // passes would be spilled, render_fused.hip)
+    auto lane_slab = [&]() -> char* { return sa.slab + (size_t)blockIdx.x * kStashBytesPerWG + (size_t)(wave * 64 + fresh_lane()) * 16; };
 
     const int tiles_c = a.NC / 16, tiles_f = (a.NC + a.NF) / 16, NT = a.NC + a.NF;
     const long long groups = (a.R + NW - 1) / NW;
@@ -231,7 +235,7 @@ __global__ void __launch_bounds__(512, 2) fused_styled_kernel(FusedStyledArgs sa
             wave_sync();
             depths(tt, tn);
             const bool last = tile + CC::NCT >= tiles_c;
-            fused_pass<PC, false, kStyledSlots>(smem, wave, lane, a.net_c, last ? sa.concat_stream : a.net_c + kNerfBiasBytes, o, d, tt, sig, col);
+            fused_pass<PC, false, kStyledSlots>(smem, wave, fresh_lane(), a.net_c, last ? sa.concat_stream : a.net_c + kNerfBiasBytes, o, d, tt, sig, col);
             depths(tt, tn);
             RayAccum acc = get_acc();
             float w[CC::NCT];
@@ -262,9 +266,11 @@ __global__ void __launch_bounds__(512, 2) fused_styled_kernel(FusedStyledArgs sa
             const int i = 16 * tile + (fresh_lane() & 15);
             float tt = s_all[i];
             const bool last = tile + 1 >= tiles_f;
-            float sig, col[3];
-            styled_pass<CF>(smem, wave, lane, sa, last ? a.net_c + kNerfBiasBytes : sa.concat_stream, o, d, tt, strip() + kStripZ,
-                            lane_slab, sig, col);
+            float col[3];
+            // (the coarse weights are dead by now: their region of the strip takes one sigma per lane)
+            styled_pass<CF>(smem, wave, fresh_lane(), sa, last ? a.net_c + kNerfBiasBytes : sa.concat_stream, o, d, tt, strip() + kStripZ,
+                            lane_slab(), strip() + kStripW + fresh_lane(), col);
+            const float sig = strip()[kStripW + fresh_lane()];
             const float* s_all2 = strip() + kStripAll;
             const int i2 = 16 * tile + (fresh_lane() & 15);
             tt = s_all2[i2];
