@@ -124,17 +124,21 @@ struct FwdArgs {
     float* sigma;          // [M]
 };
 
-__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
-    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(ushort2v, a), __builtin_bit_cast(ushort2v, b)));
+// (inline asm: __builtin_elementwise_min on a ushort2 is not selected as v_pk_min_u16 -- hipcc 7.2 expands it into SDWA
+// compares and selects, ~20 instructions per register: the gate words were 57 % of this kernel's VALU instructions)
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned ones) {
+    unsigned r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(ones));
+    return r;
 }
 // ReLU gate bits of one k-step of non-negative fp16 activations: bit (j >> 1) + 4 * (j & 1) <- element j is positive
 __device__ __forceinline__ unsigned gate_byte(half8 v) {
     const u4 w = __builtin_bit_cast(u4, v);
-    const unsigned t0 = pk_min_u16(w[0], 0x00010001u), t1 = pk_min_u16(w[1], 0x00010001u);
-    const unsigned t2 = pk_min_u16(w[2], 0x00010001u), t3 = pk_min_u16(w[3], 0x00010001u);
+    const unsigned ones = 0x00010001u;
+    const unsigned t0 = pk_min_u16(w[0], ones), t1 = pk_min_u16(w[1], ones);
+    const unsigned t2 = pk_min_u16(w[2], ones), t3 = pk_min_u16(w[3], ones);
     const unsigned b = t0 | (t1 << 1) | (t2 << 2) | (t3 << 3);   // bits 0..3: elements 0,2,4,6; bits 16..19: 1,3,5,7
-    return (b & 0xfu) | ((b >> 12) & 0xf0u);
+    return (b | (b >> 12)) & 0xffu;
 }
 template <int KS>
 __device__ __forceinline__ unsigned long long gate_word(const half8 (&h)[KS][1]) {
@@ -390,7 +394,8 @@ __device__ __forceinline__ void dgrad_epi(const float4v& acc, unsigned long long
     const float v0 = __builtin_bit_cast(float, __builtin_bit_cast(int, a0) & k0);
     const float v1 = __builtin_bit_cast(float, __builtin_bit_cast(int, a1) & k1);
     const float t0 = v0 * s_true, t1 = v1 * s_true;
-    m = fmaxf(m, fmaxf(fabsf(t0), fabsf(t1)));
+    m = fmaxf(m, fmaxf(fabsf(t0), fabsf(t1)));   // (forcing v_and / v_max3 through inline asm saves 0.25 VALU per MFMA and costs
+                                                 // 30 % of the kernel: asm statements are opaque to the MFMA / VALU interleave)
     if constexpr (HALF == 0) {
         pend[0] = t0, pend[1] = t1;
     } else {
@@ -444,8 +449,11 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
     auto seg_row = [&](int col0, int width) { return a.dz + seg_at(col0, width, m_pad, s); };
     // heads: true values to the stash (16 floats: [d sigma, dz rgb, 0 ...]), tile maximum -> first scale
     *reinterpret_cast<float4v*>(seg_row(Z_HEADS, 16) + 4 * g) = g == 0 ? float4v{hd[0], hd[1], hd[2], hd[3]} : float4v{0.f, 0.f, 0.f, 0.f};
+    // segment maxima of this wave's tile: kept (wave-uniform) until the chain is through and published then -- an atomic is
+    // a vector-memory operation, and one per layer in front of the ring's counted waits stalled every layer's first chunks
+    unsigned seg_max[11];
     float m = wave_max(fmaxf(fmaxf(fabsf(hd[0]), fabsf(hd[1])), fmaxf(fabsf(hd[2]), fabsf(hd[3]))));
-    if (lane == 0) atomicMax(a.maxima + 10, __builtin_bit_cast(unsigned, m));
+    seg_max[10] = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, m));
     int e_in = scale_exp(m, 0);
     auto heads_frag = [&](int e, half8& h, half8& l) {   // natural order k = 8g + j: the four values sit in lane group 0
         const float sc = pow2f(e);
@@ -465,9 +473,12 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
     float pend[2];
     // after a layer: the tile maximum of its gated outputs fixes the scale of the layer AFTER the next (the next layer's
     // operands were already produced at the scale derived one layer earlier); segment maxima feed the weight-gradient kernel
-    auto close = [&](int seg, float& mm, int keep) {
+    auto close = [&](auto seg_, float& mm, int keep) {
         const float t = wave_max(mm);
-        if (lane == 0) atomicMax(a.maxima + seg, __builtin_bit_cast(unsigned, t));
+        seg_max[decltype(seg_)::value] = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, t));
+#ifdef TGTC_DGRAD_ATOMIC_PER_LAYER   // A/B build: the round's first form, one atomic per layer in front of the ring waits
+        if (lane == 0) atomicMax(a.maxima + decltype(seg_)::value, __builtin_bit_cast(unsigned, t));
+#endif
         mm = 0.f;
         return scale_exp(t, keep);
     };
@@ -487,7 +498,7 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
                 dgrad_epi<rt, hf, true>(acc, gw[9], s_true, s_op, m, pend, zrow, g, Zh[rt / 2][0], Zl[rt / 2][0]);
             });
         }
-        e_next = close(9, m, e_out);
+        e_next = close(ic<9>{}, m, e_out);
         // D1: rgb_layers.0^T (activation columns): dz_f -> dz_remap
         e_in = e_out, e_out = e_next;
         {
@@ -498,7 +509,7 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
                 dgrad_epi<rt, hf, true>(acc, gw[8], s_true, s_op, m, pend, zrow, g, Yh[rt / 2][0], Yl[rt / 2][0]);
             });
         }
-        e_next = close(8, m, e_out);
+        e_next = close(ic<8>{}, m, e_out);
     }
     // D2: [base_remap^T | sigma^T]: [dz_remap | heads] -> dz_7
     e_in = e_out, e_out = e_next;
@@ -514,7 +525,7 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
             dgrad_epi<rt, hf, true>(acc, gw[7], s_true, s_op, m, pend, zrow, g, Xh[rt / 2][0], Xl[rt / 2][0]);
         });
     }
-    e_next = close(7, m, e_out);
+    e_next = close(ic<7>{}, m, e_out);
     // D3..D9: base_layers[7..1]^T: dz_l -> dz_{l-1}
     auto hidden = [&](auto d_, auto last_, const half8 (&Ih)[8][1], const half8 (&Il)[8][1], half8 (&Oh)[8][1], half8 (&Ol)[8][1]) {
         constexpr int d = decltype(d_)::value, l_out = 9 - d;          // D3 -> dz_6 ... D9 -> dz_0
@@ -526,7 +537,7 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
             constexpr int rt = decltype(rt_)::value, hf = decltype(h_)::value;
             dgrad_epi<rt, hf, !last>(acc, gw[l_out], s_true, s_op, m, pend, zrow, g, Oh[rt / 2][0], Ol[rt / 2][0]);
         });
-        e_next = close(l_out, m, e_out);
+        e_next = close(ic<l_out>{}, m, e_out);
     };
     hidden(ic<3>{}, std::false_type{}, Xh, Xl, Yh, Yl);
     hidden(ic<4>{}, std::false_type{}, Yh, Yl, Xh, Xl);
@@ -535,8 +546,19 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
     hidden(ic<7>{}, std::false_type{}, Xh, Xl, Yh, Yl);
     hidden(ic<8>{}, std::false_type{}, Yh, Yl, Xh, Xl);
     hidden(ic<9>{}, std::true_type{}, Xh, Xl, Yh, Yl);
-    // a scaled operand beyond the fp16 range would have produced infinities: report instead of returning garbage
-    if (!(m == m)) atomicMax(a.status, 1u);
+    // a scaled operand beyond the fp16 range produces infinities, which reach the maxima (fmaxf drops a NaN, not an inf):
+    // report instead of returning garbage
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) bad |= (seg_max[i] & 0x7f800000u) == 0x7f800000u;
+    // lane i publishes segment i, and only if it raises the table (one coherent load + one masked atomic per wave; after the
+    // first few tiles almost no lane has anything to add.  One unconditional atomic per wave and segment -- 90 000 on eleven
+    // addresses -- cost 0.2 ms of the kernel wherever they were issued)
+    unsigned mine = 0;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) mine = lane == i ? seg_max[i] : mine;
+    if (lane < 11 && mine > __hip_atomic_load(a.maxima + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.maxima + lane, mine);
+    if (bad && lane == 0) atomicMax(a.status, 1u);
 }
 
 }  // namespace train
