@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 outputs of tools/profile_r2.sh: per-kernel mean duration, FETCH_SIZE / WRITE_SIZE per dispatch,
+"""Summarise the rocprofv3 outputs of tools/profile_r3.sh: per-kernel mean duration, FETCH_SIZE / WRITE_SIZE per dispatch,
 SQ counters per dispatch.  Kernel names are shortened to their function name + template head."""
 import csv, glob, os, re, sys, collections
 root = sys.argv[1]
