@@ -36,7 +36,8 @@ constexpr int kTileSamples = CfgT::SAMPLES_PER_WG;
 // ------------------------------------------------------------------------------------------------ gather-pack
 // One entry per fp16 slot of a fragment stream: which parameter tensor and which element of it (or nothing) goes there.
 // The maps are built once per trainer on the host by walking the packer's loops (mlp_pack.h pack_layers), so the device
-// stream is bit-identical to what tgtc_nerf_create would pack from the same weights.
+// stream is what tgtc_nerf_create would pack from the same weights WITHOUT its power-of-two equalisation (EqualisedNet): the
+// gradients are those of the caller's tensors, row for row.
 struct PackSrc {
     int pid;   // index into the 24 parameter pointers (2 * layer: weight, 2 * layer + 1: bias), -1: zero
     int off;
