@@ -35,6 +35,16 @@ int tgtc_trainer_backward(tgtc_trainer* trainer, const float* const* params, con
                           void* stream);
 /* synchronises `stream`; non-zero (with tgtc_last_error) if the last backward overflowed its fp16 operand range */
 int tgtc_trainer_status(tgtc_trainer* trainer, void* stream);
+/* Overflow guard: a backward whose scaled gradients left the fp16 range (growth above ~2^7 across one transposed layer)
+ * ZERO-FILLS grads[0..23] on the device before it returns control to the stream -- an optimiser step on them cannot write
+ * inf / NaN into the weights -- and counts the event.  *count = such backwards since trainer_create (synchronises `stream`;
+ * read it at the reference's i_print cadence, train_tgtcs.py:257-266, not per iteration). */
+int tgtc_trainer_overflows(tgtc_trainer* trainer, void* stream, unsigned* count);
+
+/* Workspace: about 20 KB per sample -- two fp16 planes of 2 528 activations, 2 448 fp32 pre-activation gradients, one
+ * 64-bit gate word per gated layer, 16-sample tile and lane -- e.g. 2.6 GB at M = 131 072 (1 024 rays x 128 samples of the
+ * fine network).  It belongs to ONE forward / backward pair: a second forward before the backward of the first needs its
+ * own workspace (the reference's batchify, utils.py:435-456, makes two forwards before one backward). */
 
 #ifdef __cplusplus
 }

@@ -124,12 +124,15 @@ def vae_encode(sd, x, depth=4):
     return _lin(sd, "encoder.fc_layer_mu", h), _lin(sd, "encoder.fc_layer_log_var", h)
 
 
-def render_plain(sd_coarse, sd_fine, rays_o, rays_d, n_coarse, n_fine, near=0., far=1., dtype=torch.float32, dtype_fine=None):
+def render_plain(sd_coarse, sd_fine, rays_o, rays_d, n_coarse, n_fine, near=0., far=1., dtype=torch.float32, dtype_fine=None,
+                 ts_fine=None):
     """The cal_geometry chain, one chunk.  rendering.py:27-51 (perturb=False, det fine sampling).
 
     Returns dict with coarse and fine rgb_exp / t_exp / weights plus the fine t values.
     dtype / dtype_fine = float64 (with float64 state dicts): the coarse / fine half of the chain in double precision -- the
     conditioning probes of the whole-frame tests (tests/conditioning.py), not the reference's arithmetic.
+    ts_fine [R, n_coarse + n_fine] (optional): evaluate the fine network and its compositing at THESE merged depths instead
+    of the ones sampled here (conditional parity of tests/conditioning.py: the sampler's branch taken as given).
     """
     dtype_fine = dtype_fine or dtype
     pts, ts = raymarch.sample_coarse(rays_o, rays_d, n_coarse, near, far, dtype=dtype)
@@ -137,6 +140,9 @@ def render_plain(sd_coarse, sd_fine, rays_o, rays_d, n_coarse, n_fine, near=0., 
     c = style_nerf(sd_coarse, pts, dirs, dtype=dtype)
     rgb_c, t_c, w_c = raymarch.composite(c["rgb"], c["sigma"], ts)
     pts_f, ts_f = raymarch.sample_fine(rays_o, rays_d, ts.to(dtype_fine), w_c.to(dtype_fine), n_fine)
+    if ts_fine is not None:
+        ts_f = ts_fine.to(dtype_fine)
+        pts_f = rays_o[:, None, :] + rays_d[:, None, :] * ts_f[..., None]        # raymarch.sample_fine's last line (utils.py:578)
     dirs = rays_d[:, None, :].expand(-1, n_coarse + n_fine, -1)
     f = style_nerf(sd_fine, pts_f, dirs, dtype=dtype_fine)
     rgb_f, t_f, w_f = raymarch.composite(f["rgb"], f["sigma"], ts_f)
@@ -161,13 +167,16 @@ def _styled_pass(sd_nerf, sd_concat, sd_style, pts, dirs, z, dtype=torch.float32
 
 
 def render_styled(sd_coarse, sd_fine, sd_concat, sd_style, rays_o, rays_d, z,
-                  n_coarse, n_fine, near=0., far=1., jitter=None, dtype=torch.float32):
-    """The render_style chain, one batch.  rendering.py:118-178.  dtype=float64: see render_plain."""
+                  n_coarse, n_fine, near=0., far=1., jitter=None, dtype=torch.float32, ts_fine=None):
+    """The render_style chain, one batch.  rendering.py:118-178.  dtype=float64, ts_fine: see render_plain."""
     pts, ts = raymarch.sample_coarse(rays_o, rays_d, n_coarse, near, far, jitter, dtype=dtype)
     dirs = rays_d[:, None, :].expand(-1, n_coarse, -1)
     rgb, sig = _styled_pass(sd_coarse, sd_concat, sd_style, pts, dirs, z, dtype)
     rgb_c, t_c, w_c = raymarch.composite(rgb, sig, ts)
     pts_f, ts_f = raymarch.sample_fine(rays_o, rays_d, ts, w_c, n_fine)
+    if ts_fine is not None:
+        ts_f = ts_fine.to(ts.dtype)
+        pts_f = rays_o[:, None, :] + rays_d[:, None, :] * ts_f[..., None]
     dirs = rays_d[:, None, :].expand(-1, n_coarse + n_fine, -1)
     rgb, sig = _styled_pass(sd_fine, sd_concat, sd_style, pts_f, dirs, z, dtype)
     rgb_f, t_f, w_f = raymarch.composite(rgb, sig, ts_f)

@@ -354,20 +354,47 @@ def test_cal_geometry_files_match_reference_written_files(tmp_path):
     class Loader(list):
         dataset = DS
     batches = Loader({"rays_o": torch.from_numpy(ro[i:i + 40]), "rays_d": torch.from_numpy(rd[i:i + 40])} for i in range(0, n, 40))
-    rendering.cal_geometry(dataloader=batches, sv_path=str(tmp_path), samp_func=utils.sampling_pts_uniform,
-                           samp_func_fine=utils.sampling_pts_fine_torch, args=args, device="cuda",
-                           model_forward=utils.batchify(lambda **k: nets[0](**k), 32),
-                           model_forward_fine=utils.batchify(lambda **k: nets[1](**k), 32),
-                           renderer=rendering.RayRenderer(*nets))
+    rgb_map, t_map = rendering.cal_geometry(dataloader=batches, sv_path=str(tmp_path), samp_func=utils.sampling_pts_uniform,
+                                            samp_func_fine=utils.sampling_pts_fine_torch, args=args, device="cuda",
+                                            model_forward=utils.batchify(lambda **k: nets[0](**k), 32),
+                                            model_forward_fine=utils.batchify(lambda **k: nets[1](**k), 32),
+                                            renderer=rendering.RayRenderer(*nets))
+    # the rendered rays under the frozen parity criterion (tests/conditioning.py), the float32 oracle standing for the reference
+    import conditioning
+    from oracle import fields
+    sds = [synth.nerf_state(0), synth.nerf_state(1)]
+    td = lambda sd, dt: {k: v.to(dt) for k, v in t(sd).items()}
+    tro, trd = torch.from_numpy(ro), torch.from_numpy(rd)
+    render = lambda o, d, dc, df, sel, **kw: fields.render_plain(td(sds[0], dc), td(sds[1], df), o, d, 64, 64, dtype=dc, dtype_fine=df, **kw)
+    e, ill = conditioning.check("cal_geometry 64c+64f", torch.as_tensor(rgb_map).reshape(-1, 3), torch.as_tensor(t_map).reshape(-1), render,
+                              tro, trd, n_fine=64, max_certified=0.03,
+                              stages=lambda sel: conditioning.hip_stages(nets[0], tro[sel].cuda(), trd[sel].cuda(), 64, 64))
+    t32 = render(tro, trd, torch.float32, torch.float32, None)["t_fine"].numpy()
+    strict = np.abs(np.asarray(torch.as_tensor(t_map).reshape(-1).cpu()) - t32) <= 1e-3        # rays on the float32 reference's own branch
     for name in ("geometry_00001.npz", "geometry.npz"):
         ref, mine = np.load(os.path.join(files, name)), np.load(os.path.join(str(tmp_path), name))
         assert sorted(mine.files) == sorted(ref.files), name
         for k in ref.files:
             assert mine[k].shape == ref[k].shape and mine[k].dtype == ref[k].dtype, (name, k, mine[k].dtype, ref[k].dtype)
             d = np.abs(mine[k].astype(np.float64) - ref[k].astype(np.float64))
-            # coor_map = o + t * d per pixel: 1e-3 except on the few rays where the reference chain is itself discontinuous at the
-            # rounding level (tests/conditioning.py; at 64c+64f such a ray's depth can move by a coarse bin, 1/64 of |d| = 2)
-            assert np.mean(d <= 1e-3) >= 0.97 and d.max() <= 0.1, (name, k, float(d.max()), float(np.mean(d <= 1e-3)))
+            if k != "coor_map":
+                assert d.max() <= 1e-6, (name, k, float(d.max()))
+                continue
+            # coor_map = o + t * d per pixel (|d| <= 2.1): the file the REFERENCE wrote is the float32 oracle's (1e-5 on the rays
+            # that are well conditioned -- on the others the float32 oracle itself depends on the CPU it runs on: the file was
+            # written in the build container, this oracle runs on the GPU box's host, and round 4's first run of this test saw
+            # them differ), and on every ray whose depth is within 1e-3 of that oracle the coordinates agree to 1e-3 * |d|; the
+            # other rays (the sampler's other branch) are the ones conditioning.check has just accounted for, one by one
+            rays = slice(48, 96) if name == "geometry_00001.npz" else slice(0, n)
+            ref_pts = (ro[rays] + t32[rays, None] * rd[rays]).reshape(ref[k].shape)
+            well = ~ill.numpy()[rays]
+            dref = np.abs(ref[k] - ref_pts).reshape(-1, 3).max(1)
+            print("%s: reference-written file vs the float32 oracle run HERE: %.2e on the %d well-conditioned rays, %.2e on the other %d" % (
+                name, dref[well].max(), int(well.sum()), dref[~well].max() if (~well).any() else 0.0, int((~well).sum())))
+            assert dref[well].max() <= 1e-5, (name, "the reference-written file is not the float32 oracle's output", float(dref[well].max()))
+            dr = d.reshape(-1, 3).max(1)
+            assert dr[strict[rays]].max() <= 2.1e-3, (name, k, float(dr[strict[rays]].max()))
+            assert strict[rays].mean() >= 0.95, (name, float(strict[rays].mean()))
 
 
 @pytest.mark.parametrize("scene", ["fern", "flower", "horns", "orchids", "trex"])
@@ -394,5 +421,8 @@ def test_every_llff_config_inside_1e3_at_the_headline_precision(scene):
     import conditioning
     td = lambda sd, dt: {k: v.to(dt) for k, v in t(sd).items()}
     conditioning.check("%s %dc+%df" % (scene, args.N_samples, args.N_samples_fine), out["rgb"], out["t"],
-                       lambda o, d, dc, df, sel: fields.render_plain(td(sds[0], dc), td(sds[1], df), o, d, args.N_samples, args.N_samples_fine,
-                                                                     dtype=dc, dtype_fine=df), ro.cpu(), rd.cpu(), tol=1e-3, max_ill=0.2)
+                       lambda o, d, dc, df, sel, **kw: fields.render_plain(td(sds[0], dc), td(sds[1], df), o, d, args.N_samples, args.N_samples_fine,
+                                                                           dtype=dc, dtype_fine=df, **kw), ro.cpu(), rd.cpu(), tol=1e-3,
+                       n_fine=args.N_samples_fine,
+                       stages=lambda sel: conditioning.hip_stages(nets[0], ro[sel.cuda()].contiguous(), rd[sel.cuda()].contiguous(),
+                                                                  args.N_samples, args.N_samples_fine))

@@ -171,6 +171,84 @@ def test_fused_training_path_matches_the_unfused_one():
             assert float(db.abs().max()) <= 3e-5 * sb, (M, l, "bias", float(db.abs().max()) / sb, S[:10].tolist())
 
 
+def test_two_forwards_before_one_backward_keep_their_own_stash():
+    """the reference's Origin_train calls the net through utils.batchify (utils.py:435-456), i.e. TWO forwards of
+    32 768 samples before ONE backward; the fused path's activation stash must belong to the call, not to the trainer.  The
+    chunked forward + one backward equals the one-call forward + backward, and equals the per-layer path's chunked run."""
+    from tgtc_style_amd import fused_train, models, utils
+    M, chunk = 3000, 1024                     # three chunks, the last one ragged
+    rng = np.random.default_rng(77)
+    pts = torch.from_numpy(rng.uniform(-1.2, 1.2, (M, 3))).cuda()
+    dirs = torch.from_numpy(rng.uniform(-1, 1, (M, 3))).cuda()
+    g_rgb = torch.from_numpy(rng.standard_normal((M, 3)).astype(np.float32) * 1e-3).cuda()
+    g_sig = torch.from_numpy(rng.standard_normal(M).astype(np.float32) * 1e-5).cuda()
+    res = {}
+    for tag, fused, chunked in (("fused-chunked", True, True), ("fused-whole", True, False), ("layers-chunked", False, True)):
+        m = models.StyleNerf(Args, mode="fine")
+        m.load_state_dict(T(synth.nerf_state(1)))
+        m = m.cuda().trainable(fused=fused)
+        fwd = utils.batchify(lambda **k: m(**k), chunk) if chunked else (lambda **k: m(**k))
+        out = fwd(pts=pts, dirs=dirs)
+        ((out["rgb"] * g_rgb).sum() + (out["sigma"] * g_sig).sum()).backward()
+        res[tag] = (out["rgb"].detach(), out["sigma"].detach(), [p.grad.clone() for p in fused_train.mlp_parameters(m.net)])
+        if fused:
+            m._trainer.status()
+            assert m.training_overflows() == 0
+    a, b, c = res["fused-chunked"], res["fused-whole"], res["layers-chunked"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])                    # the forward does not depend on the chunking
+    for l in range(24):
+        scale = float(b[2][l].abs().max()) + 1e-30
+        # same samples, same gates (bit-identical forwards): only the order of the fp32 atomics in the weight gradients differs
+        assert float((a[2][l] - b[2][l]).abs().max()) <= 2e-5 * scale, ("chunked vs whole", l, float((a[2][l] - b[2][l]).abs().max()) / scale)
+        # and the per-layer path on the same chunks agrees up to the few rank-one gate-flip terms of the test above: 5 % raw
+        assert float((a[2][l] - c[2][l]).abs().max()) <= 5e-2 * (float(c[2][l].abs().max()) + 1e-30), ("fused vs layers", l)
+    # with a stash shared between calls the first chunk's gradients would have been computed from the LAST chunk's activations:
+    # show that this test can see it -- the gradient of the first chunk alone is far from that of the last chunk alone
+    m = models.StyleNerf(Args, mode="fine")
+    m.load_state_dict(T(synth.nerf_state(1)))
+    m = m.cuda().trainable()
+    parts = []
+    for lo in (0, 2 * chunk):
+        m.zero_grad()
+        out = m(pts=pts[lo:lo + chunk], dirs=dirs[lo:lo + chunk])
+        ((out["rgb"] * g_rgb[lo:lo + chunk]).sum() + (out["sigma"] * g_sig[lo:lo + chunk]).sum()).backward()
+        parts.append(fused_train.mlp_parameters(m.net)[2].grad.clone())
+    assert float((parts[0] - parts[1]).abs().max()) > 0.2 * float(parts[0].abs().max())
+
+
+def test_overflow_guard_zero_fills_the_gradients():
+    """growth above ~2^7 in one transposed layer overflows the fp16 operands of the input-gradient chain; the
+    gradients would be inf / NaN and an Adam step would destroy the weights.  The library's guard zero-fills them on the device
+    and counts the event; a normal backward afterwards works and leaves the count alone."""
+    from tgtc_style_amd import fused_train, models
+    M = 512
+    rng = np.random.default_rng(5)
+    pts = torch.from_numpy(rng.uniform(-1.2, 1.2, (M, 3))).cuda()
+    dirs = torch.from_numpy(rng.uniform(-1, 1, (M, 3))).cuda()
+    sd = {k: v.copy() for k, v in synth.nerf_state(1).items()}
+    sd["net.base_layers.6.weight"] *= 3.0e4          # dL/dh grows by ~2^15 across this transposed layer
+    m = models.StyleNerf(Args, mode="fine")
+    m.load_state_dict(T(sd))
+    m = m.cuda().trainable()
+    before = m.training_overflows()
+    out = m(pts=pts, dirs=dirs)
+    (out["rgb"].sum() + out["sigma"].sum()).backward()
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        m._trainer.status()
+    assert m.training_overflows() == before + 1
+    for p in fused_train.mlp_parameters(m.net):
+        assert bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) == 0.0
+    # a well-scaled network on the same trainer: finite, non-zero gradients, counter unchanged
+    m.load_state_dict({k: v.cuda() for k, v in T(synth.nerf_state(1)).items()})
+    m.zero_grad()
+    out = m(pts=pts, dirs=dirs)
+    (out["rgb"].sum() + out["sigma"].sum()).backward()
+    m._trainer.status()
+    assert m.training_overflows() == before + 1
+    assert all(bool(torch.isfinite(p.grad).all()) for p in fused_train.mlp_parameters(m.net))
+    assert float(fused_train.mlp_parameters(m.net)[0].grad.abs().max()) > 0
+
+
 def test_style_mlp_gradients_match_the_oracle():
     """The two style MLPs marked trainable: gradients w.r.t. every weight, the latent and the concat features against
     float64 autograd on the oracle (Style_train's differentiable pieces, train_tgtcs.py:312-571)."""

@@ -83,8 +83,9 @@ def test_headline_precision_on_heavy_tailed_weights(golden):
         out = r.render(ro, rd, NC, NF)
         rgb, t = out["rgb"].cpu(), out["t"].cpu()
         assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(t).all())
-        render = lambda o, d, dc, df, sel: fields.render_plain(T(sc, dc), T(sf, df), o, d, NC, NF, dtype=dc, dtype_fine=df)
-        # every ray within 1e-3 of an admissible output of the reference (tests/conditioning.py); no exemptions
-        e, ill = conditioning.check("%-9s set %d" % (family, k), rgb, t, render, ro.cpu(), rd.cpu(), tol=1e-3)
+        render = lambda o, d, dc, df, sel, **kw: fields.render_plain(T(sc, dc), T(sf, df), o, d, NC, NF, dtype=dc, dtype_fine=df, **kw)
+        # every ray within 1e-3 of an admissible output of the reference or stage-certified (tests/conditioning.py); no exemptions
+        e, ill = conditioning.check("%-9s set %d" % (family, k), rgb, t, render, ro.cpu(), rd.cpu(), tol=1e-3, n_fine=NF,
+                                    stages=lambda sel, c=nets[0], o=ro, d=rd: conditioning.hip_stages(c, o[sel.cuda()].contiguous(), d[sel.cuda()].contiguous(), NC, NF))
         worst = max(worst, float(e.max()))
     print("worst case %.2e: margin %.1fx inside 1e-3" % (worst, 1e-3 / worst))

@@ -45,13 +45,15 @@ def nets(precision="fp16x3"):
     return a, out
 
 
-def check_against_oracle(label, rgb, t, render, ro, rd, median_bound=1e-5, mixed=True):
+def check_against_oracle(label, rgb, t, render, ro, rd, coarse, median_bound=1e-5, mixed=True):
     """Every spot-check ray within 1e-3 of an admissible output of the reference (tests/conditioning.py: the float32 oracle,
     or the branch the reference itself takes when its arithmetic is perturbed at the rounding level); no ray is exempt.  The
     median against the float32 oracle must sit at the precision mode's own level (fp32 rounding for fp16x3, the fp6
     correction's ~1e-4 for a fine pass in fp16mx)."""
     import conditioning
-    conditioning.check(label, rgb, t, render, ro, rd, tol=1e-3, median_bound=median_bound, mixed=mixed)
+    # `coarse`: the coarse StyleNerf, for the stage certificate of rays the fixed variant set does not explain
+    conditioning.check(label, rgb, t, render, ro, rd, tol=1e-3, median_bound=median_bound, mixed=mixed, n_fine=NF,
+                       stages=lambda sel: conditioning.hip_stages(coarse, ro[sel].cuda(), rd[sel].cuda(), NC, NF))
 
 
 def spot_indices(H, W, per_band=400):
@@ -84,9 +86,9 @@ def test_whole_frame_plain(scene, precision):
     idx = spot_indices(H, W)
     assert idx.numel() >= 1200 and int(idx[-1]) == n - 1
     check_against_oracle("%s %dx%d plain %s" % (scene, W, H, precision), rgb[idx], t[idx],
-                         lambda o, d, dc, df, sel: fields.render_plain(T(synth.nerf_state(0), dc), T(synth.nerf_state(1), df), o, d, NC, NF,
-                                                                  dtype=dc, dtype_fine=df),
-                         ro[idx].cpu(), rd[idx].cpu(), median_bound=1e-5 if precision == "fp16x3" else 2e-4)
+                         lambda o, d, dc, df, sel, **kw: fields.render_plain(T(synth.nerf_state(0), dc), T(synth.nerf_state(1), df), o, d, NC, NF,
+                                                                        dtype=dc, dtype_fine=df, **kw),
+                         ro[idx].cpu(), rd[idx].cpu(), coarse, median_bound=1e-5 if precision == "fp16x3" else 2e-4)
     if scene != "trex":
         return
     # config 4: eight contiguous ray ranges; every rank's range alone reproduces the whole-frame bits
@@ -123,11 +125,11 @@ def test_whole_frame_styled(scene):
     raw = [synth.nerf_state(0), synth.nerf_state(1), synth.concat_state(2), synth.style_state(3)]
     zi = z[idx].cpu()
 
-    def oracle(o, d, dc, df, sel):          # the stylised chain has one dtype (dc); sel = subset of the spot-check rays
+    def oracle(o, d, dc, df, sel, **kw):    # the stylised chain has one dtype (dc); sel = subset of the spot-check rays
         zz = (zi if sel is None else zi[sel]).to(dc)
         w = [T(sd, dc) for sd in raw]
-        return fields.render_styled(w[0], w[1], w[2], w[3], o, d, zz, NC, NF, dtype=dc)
-    check_against_oracle("%s %dx%d styled" % (scene, W, H), rgb[idx], t[idx], oracle, ro[idx].cpu(), rd[idx].cpu(), mixed=False)
+        return fields.render_styled(w[0], w[1], w[2], w[3], o, d, zz, NC, NF, dtype=dc, **kw)
+    check_against_oracle("%s %dx%d styled" % (scene, W, H), rgb[idx], t[idx], oracle, ro[idx].cpu(), rd[idx].cpu(), coarse, mixed=False)
     if scene != "trex":
         return
     for rank in (0, 3, 7):          # first, an interior and the last rank of the 8-way split

@@ -879,6 +879,21 @@ extern "C" int tgtc_trainer_create(tgtc_trainer** out) {
     return TGTC_OK;
 }
 
+// Overflow guard: the input-gradient chain raises `status` when a scaled operand left the fp16 range -- its
+// gradients are then inf / NaN, and an optimiser step would destroy the weights for good.  Runs last in every backward:
+// if the flag is set it zero-fills all 24 gradient tensors (the step becomes a no-op apart from the optimiser's momentum)
+// and counts the event in a word that survives the per-call reset (tgtc_trainer_overflows).
+struct GuardArgs {
+    float* g[24];
+    unsigned n[24];
+};
+__global__ void __launch_bounds__(256) overflow_guard_kernel(const unsigned* status, unsigned* count, GuardArgs a) {
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    for (int i = 0; i < 24; ++i)
+        for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < a.n[i]; k += gridDim.x * blockDim.x) a.g[i][k] = 0.0f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(count, 1u);
+}
+
 extern "C" int tgtc_trainer_destroy(tgtc_trainer* tr) {
     if (!tr) return TGTC_OK;
     const hipError_t e = tr->dev ? hipFree(tr->dev) : hipSuccess;
@@ -938,7 +953,7 @@ extern "C" int tgtc_trainer_backward(tgtc_trainer* tr, const float* const* param
                                                                     reinterpret_cast<half_t*>(bs + kNerfBiasBytes), nullptr, 0, nullptr);
     TGTC_LAUNCH_CHECK();
     unsigned* maxima = reinterpret_cast<unsigned*>(tr->dev + tr->maxima_off);
-    TGTC_HIP_CHECK(hipMemsetAsync(maxima, 0, 64, st));
+    TGTC_HIP_CHECK(hipMemsetAsync(maxima, 0, 52, st));    // 11 segment maxima, status word at +48; the overflow counter at +52 survives
     static const int shape[12][2] = {{256, 63}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 319}, {256, 256}, {256, 256},
                                      {1, 256},  {256, 256}, {128, 283}, {3, 128}};
     {   // the weight-gradient kernel accumulates: zero-fill first (ONE fill when the caller laid the 24 tensors out back to back)
@@ -976,6 +991,20 @@ extern "C" int tgtc_trainer_backward(tgtc_trainer* tr, const float* const* param
     TGTC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(train_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kWgLdsBytes));
     train_wgrad_kernel<<<(unsigned)g.chunk0[kWgradJobs], 512, kWgLdsBytes, st>>>(g);
     TGTC_LAUNCH_CHECK();
+    GuardArgs ga{};
+    for (int l = 0; l < 12; ++l) {
+        ga.g[2 * l] = grads[2 * l], ga.n[2 * l] = (unsigned)(shape[l][0] * shape[l][1]);
+        ga.g[2 * l + 1] = grads[2 * l + 1], ga.n[2 * l + 1] = (unsigned)shape[l][0];
+    }
+    overflow_guard_kernel<<<64, 256, 0, st>>>(maxima + 12, maxima + 13, ga);
+    TGTC_LAUNCH_CHECK();
+    return TGTC_OK;
+}
+
+extern "C" int tgtc_trainer_overflows(tgtc_trainer* tr, void* stream, unsigned* count) {
+    TGTC_REQUIRE(tr && count, "trainer_overflows: null argument");
+    TGTC_HIP_CHECK(hipMemcpyAsync(count, tr->dev + tr->maxima_off + 52, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    TGTC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     return TGTC_OK;
 }
 

@@ -23,6 +23,7 @@ SIGNATURES = {
     "tgtc_trainer_forward": [c_void_p, _PTRS, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p],
     "tgtc_trainer_backward": [c_void_p, _PTRS, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, _PTRS, c_void_p],
     "tgtc_trainer_status": [c_void_p, c_void_p],
+    "tgtc_trainer_overflows": [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_uint)],
 }
 hip.register(SIGNATURES, {"tgtc_trainer_workspace_bytes": c_size_t})
 
@@ -44,13 +45,22 @@ def _table(tensors):
     return arr
 
 
+MAX_WORKSPACE_BYTES = 96 << 30     # a third of the card: beyond it the caller should chunk the batch (20 KB per sample)
+
+
 class NerfTrainer:
+    """Workspaces (activation stash, gate words, pre-activation gradients: ~20 KB per sample, include/tgtc_train.h) belong
+    to ONE forward / backward pair: `lease` hands one out per forward, the autograd node keeps it until its backward has
+    run and `release` returns it to the pool.  Two forwards before one backward -- the reference's batchify
+    (utils.py:435-456), gradient accumulation -- therefore hold two workspaces; `drop_workspaces` frees the pool
+    (StyleNerf.trainable(False))."""
+
     def __init__(self):
         self.lib = hip.load()
         h = c_void_p()
         hip.check(self.lib.tgtc_trainer_create(ctypes.byref(h)))
         self.handle = h
-        self._ws = None
+        self._pool = []
 
     def __del__(self):
         try:
@@ -59,27 +69,39 @@ class NerfTrainer:
         except Exception:
             pass
 
-    def workspace(self, M, device):
+    def lease(self, M, device):
+        """a workspace for one forward / backward pair of M samples"""
         need = int(self.lib.tgtc_trainer_workspace_bytes(M))
+        if need > MAX_WORKSPACE_BYTES:
+            raise ValueError("fused training workspace for %d samples = %.1f GiB (about 20 KB per sample): chunk the batch "
+                             "(utils.batchify) or train on the per-layer path (.trainable(fused=False))" % (M, need / 2.0 ** 30))
         device = torch.device(device)
         if device.type == "cuda" and device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
-        return self._ws
+        for i, ws in enumerate(self._pool):
+            if ws.numel() >= need and ws.device == device:
+                return self._pool.pop(i)
+        return torch.empty(need, dtype=torch.uint8, device=device)
 
-    def forward(self, params, pts, dirs):
+    def release(self, ws):
+        if ws is not None and len(self._pool) < 4:
+            self._pool.append(ws)
+
+    def drop_workspaces(self):
+        self._pool = []
+
+    def forward(self, params, pts, dirs, ws):
         M, dev = pts.shape[0], pts.device
-        ws = self.workspace(M, dev)
         rgb = torch.empty(M, 3, device=dev, dtype=torch.float32)
         sigma = torch.empty(M, device=dev, dtype=torch.float32)
         hip.check(self.lib.tgtc_trainer_forward(self.handle, _table(params), hip.ptr(pts), hip.ptr(dirs), M, hip.ptr(ws), ws.numel(),
                                                 hip.ptr(rgb), hip.ptr(sigma), hip.stream()))
         return rgb, sigma
 
-    def backward(self, params, rgb, d_rgb, d_sigma):
+    def backward(self, params, rgb, d_rgb, d_sigma, ws):
+        """gradients of the 24 parameters; zero-filled by the library's overflow guard when the scaled input gradients left
+        the fp16 range (include/tgtc_train.h, `overflows`)"""
         M = rgb.shape[0]
-        ws = self.workspace(M, rgb.device)
         flat = torch.empty(sum(p.numel() for p in params), device=rgb.device, dtype=torch.float32)     # back to back: one zero-fill
         grads, at = [], 0
         for p in params:
@@ -91,6 +113,13 @@ class NerfTrainer:
 
     def status(self):
         hip.check(self.lib.tgtc_trainer_status(self.handle, hip.stream()))
+
+    def overflows(self):
+        """backwards since creation whose gradients the overflow guard zero-filled (synchronises; read it at the reference's
+        i_print cadence, train_tgtcs.py:257-266)"""
+        n = ctypes.c_uint(0)
+        hip.check(self.lib.tgtc_trainer_overflows(self.handle, hip.stream(), ctypes.byref(n)))
+        return int(n.value)
 
     def apply(self, net, pts, dirs):
         """pts, dirs: [..., 3] (any float dtype) -> rgb [..., 3], sigma [...]"""
@@ -106,8 +135,9 @@ class _NerfTrainFn(torch.autograd.Function):
     def forward(ctx, trainer, pts, dirs, *params):
         hip.require_gpu(pts, dirs, *params)
         ps = [p.detach().float().contiguous() for p in params]
-        rgb, sigma = trainer.forward(ps, pts, dirs)
-        ctx.trainer, ctx.ps = trainer, ps
+        ws = trainer.lease(pts.shape[0], pts.device)
+        rgb, sigma = trainer.forward(ps, pts, dirs, ws)
+        ctx.trainer, ctx.ps, ctx.ws = trainer, ps, ws          # the stash of THIS call, until its backward has run
         ctx.save_for_backward(rgb)
         ctx.mark_non_differentiable()
         return rgb, sigma
@@ -118,5 +148,10 @@ class _NerfTrainFn(torch.autograd.Function):
         M = rgb.shape[0]
         d_rgb = torch.zeros_like(rgb) if d_rgb is None else d_rgb.float().contiguous()
         d_sigma = torch.zeros(M, device=rgb.device) if d_sigma is None else d_sigma.float().contiguous()
-        grads = ctx.trainer.backward(ctx.ps, rgb, d_rgb, d_sigma)
+        if ctx.ws is None:
+            raise RuntimeError("fused NeRF training: backward called twice on one forward (retain_graph): the activation stash "
+                               "was returned to the pool after the first backward")
+        grads = ctx.trainer.backward(ctx.ps, rgb, d_rgb, d_sigma, ctx.ws)
+        ctx.trainer.release(ctx.ws)
+        ctx.ws = None
         return (None, None, None) + tuple(grads)

@@ -176,7 +176,15 @@ class StyleNerf(nn.Module):
         if self.fused_training and self._trainer is None:
             from . import fused_train
             self._trainer = fused_train.NerfTrainer()
+        if not on and self._trainer is not None:
+            self._trainer.drop_workspaces()         # ~20 KB per sample of the largest batch seen (fused_train.NerfTrainer)
         return self
+
+    def training_overflows(self):
+        """Backwards of the fused training path whose gradients were zero-filled by the library's overflow guard (the scaled
+        input gradients left the fp16 range; include/tgtc_train.h).  Synchronises: read it where the reference prints its
+        losses (every i_print iterations, train_tgtcs.py:257-266)."""
+        return 0 if self._trainer is None else self._trainer.overflows()
 
     def set_enable_style(self, enable_style=False):
         self.enable_style = enable_style

@@ -43,6 +43,15 @@ __global__ void __launch_bounds__(256) k(const int* seed, float* out, long long*
                 half8 ha = __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7), hb = __builtin_shufflevector(v, v, 8, 9, 10, 11, 12, 13, 14, 15);
                 if (u == 1 || u == 4) acc[1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, acc[1], 2, 2, 0, sa, 0, sb);
                 else if (u < 6) acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, acc[0], 0, 0, 0);
+            } else if (MODE == 6 || MODE == 7) {  // M C M M C M on ONE chain (6) / alternating between two chains (7: the 128-deep blocks of a row tile)
+                half8 ha = __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7), hb = __builtin_shufflevector(v, v, 8, 9, 10, 11, 12, 13, 14, 15);
+                if (u < 6) {
+#pragma unroll
+                    for (int c = 0; c < (MODE == 7 ? 2 : 1); ++c) {
+                        if (u == 1 || u == 4) acc[c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, acc[c], 2, 2, 0, sa, 0, sb);
+                        else acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, acc[c], 0, 0, 0);
+                    }
+                }
             } else if (MODE == 5) {  // f16 MFMA, 4 independent chains
                 half8 ha = __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7), hb = __builtin_shufflevector(v, v, 8, 9, 10, 11, 12, 13, 14, 15);
                 acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, acc[u & 3], 0, 0, 0);
@@ -63,10 +72,11 @@ int main() {
     int* dseed; float* dout; long long* dclk;
     CK(hipMalloc(&dseed, 4096)); CK(hipMalloc(&dout, 1024 * 256 * 4)); CK(hipMalloc(&dclk, 1024 * 8));
     CK(hipMemcpy(dseed, seed.data(), 4096, hipMemcpyHostToDevice));
-    const char* names[6] = {"cvt_pk32_fp6_f16", "fp6 mfma 4 chains", "fp6 mfma dependent", "f16 mfma dependent", "group M C M M C M (per 8 slots, 6 used)", "f16 mfma 4 chains"};
+    const char* names[8] = {"cvt_pk32_fp6_f16", "fp6 mfma 4 chains", "fp6 mfma dependent", "f16 mfma dependent", "group M C M M C M (per 8 slots, 6 used)", "f16 mfma 4 chains",
+                            "group M C M M C M on ONE chain (6 MFMA per 8 slots)", "the same on two alternating chains (12 MFMA per 8 slots)"};
     const int iters = 2000;
     for (int waves = 1; waves <= 2; ++waves)
-        for (int mode = 0; mode < 6; ++mode) {
+        for (int mode = 0; mode < 8; ++mode) {
             const int blocks = 256 * waves;
             switch (mode) {
                 case 0: k<0><<<blocks, 256>>>(dseed, dout, dclk, iters); break;
@@ -75,6 +85,8 @@ int main() {
                 case 3: k<3><<<blocks, 256>>>(dseed, dout, dclk, iters); break;
                 case 4: k<4><<<blocks, 256>>>(dseed, dout, dclk, iters); break;
                 case 5: k<5><<<blocks, 256>>>(dseed, dout, dclk, iters); break;
+                case 6: k<6><<<blocks, 256>>>(dseed, dout, dclk, iters); break;
+                case 7: k<7><<<blocks, 256>>>(dseed, dout, dclk, iters); break;
             }
             CK(hipDeviceSynchronize());
             std::vector<long long> clk(blocks);

@@ -66,8 +66,10 @@ grad_ref = {}
 
 
 def train_once(i):
-    rgb, sigma = tr.forward(params, pts[i], dirs)
-    grads = tr.backward(params, rgb, g_rgb, g_sig)
+    ws = tr.lease(pts[i].shape[0], pts[i].device)
+    rgb, sigma = tr.forward(params, pts[i], dirs, ws)
+    grads = tr.backward(params, rgb, g_rgb, g_sig, ws)
+    tr.release(ws)
     tr.status()
     flat = torch.cat([g.reshape(-1) for g in grads])
     if i not in grad_ref:
