@@ -42,6 +42,7 @@ FLOP_PER_RAY = 2 * (N_COARSE * MAC_SIGMA + (N_COARSE + N_FINE) * MAC_FULL)      
 FLOP_PER_RAY_STYLED = 2 * (N_COARSE * MAC_SIGMA + (N_COARSE + N_FINE) * MAC_STYLED)   # 704.4 MFLOP
 PEAK_FP16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
 BYTES_PER_RAY = 2 * 3 * 8 + 16   # float64 origin + direction in, RGB + depth out (SURVEY 8d counts float32 rays: 24 + 16)
+BYTES_PER_RAY_STYLED = BYTES_PER_RAY + 32 * 4   # + the ray's 32-float style latent
 # MFMA issue slots per algorithmic product: fp16x3 = hi*hi + lo*hi + hi*lo; fp16mx = 4 f16 + 2 fp6 16x16x128 per 128-deep block
 MFMA_PER_PRODUCT = {"fp16x3": 3.0, "fp16": 1.0, "fp16mx": 1.5}
 DTYPE = {"fp16x3": "f16 MFMA operands split hi+lo (3 products), f32 accumulate",
@@ -94,8 +95,8 @@ def cpu_baseline(n_rays, chunk=1024):
     bounded sample of the same workload; same chunking as the reference CLI (--chunk 1024)."""
     from oracle import fields, rays
     from tgtc_style_amd import synth
-    # a one-GPU box gives this job a 16-CPU share; more torch threads than that only thrash
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    # every core this job may run on (BASELINE.md section 3: "all physical cores, stated"); the box's total is reported next to it
+    cores = len(os.sched_getaffinity(0))
     torch.set_num_threads(cores)
     c, f = t_state(synth.nerf_state(0)), t_state(synth.nerf_state(1))
     o, d = rays.frame_rays_ndc(H, W, synth.fern_intrinsics(H, W), synth.spiral_pose(0))
@@ -106,9 +107,10 @@ def cpu_baseline(n_rays, chunk=1024):
         for lo in range(chunk, chunk + n_rays, chunk):
             fields.render_plain(c, f, o[lo:lo + chunk], d[lo:lo + chunk], N_COARSE, N_FINE)
         dt = time.perf_counter() - t0
-    return {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port", "host_cpus": os.cpu_count(),
             "sample": "%d rays of the same 400x400 frame in chunks of %d after one warm-up chunk, "
-                      "torch %s CPU fp32, %d threads, %.1f s" % (n_rays, chunk, torch.__version__, cores, dt)}
+                      "torch %s CPU fp32, %d threads = every CPU of this job's affinity mask (the host has %s), %.1f s" % (
+                          n_rays, chunk, torch.__version__, cores, os.cpu_count(), dt)}
 
 
 def pmc_traffic(kernel):
@@ -334,11 +336,15 @@ def bench_frame(precision, h, w, steps, warmup, styled=False):
     dt, ms, out = time_loop(lambda i: r.render(*rays[i % 2], N_COARSE, N_FINE, near=0., far=1., z=z), steps, warmup)
     assert bool(torch.isfinite(out["rgb"]).all()) and bool(torch.isfinite(out["t"]).all())
     flop = (FLOP_PER_RAY_STYLED if styled else FLOP_PER_RAY) * n
+    roof = {"bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+            "frac": flop / (ms * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, "kernel_ms": ms, "algorithmic_tflop_per_launch": flop / 1e12}
+    if styled and (h, w) == (H, W):     # the PMC passes of tools/profile_r*.sh profiled whole 400x400 stylised frames
+        traffic, provenance = pmc_traffic("styled:fp16x3+fp16mx")
+        algo = n * BYTES_PER_RAY_STYLED
+        roof.update(traffic=traffic, traffic_source=provenance, algorithmic_bytes_per_launch=algo,
+                    traffic_over_algorithmic=(traffic / algo) if traffic else None)
     return {"value": n * steps / dt, "unit": "rays/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": precision,
-            "rays_per_step": n, "kernel_ms": ms,
-            "roofline": {"bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flop / (ms * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, "kernel_ms": ms,
-                         "algorithmic_tflop_per_launch": flop / 1e12}}
+            "rays_per_step": n, "kernel_ms": ms, "roofline": roof}
 
 
 def run_headline(args, precision, rank, world, dist):

@@ -7,7 +7,7 @@
 // order (no FMA contraction where the reference has separate roundings) so float64 outputs agree to
 // the last bits and float32 outputs to ~1 ulp.
 #include "common.h"
-#include "raymarch_dev.h"
+#include "raymarch_wave.h"
 
 // The reference evaluates these formulas with separate multiplies and adds (numpy / ATen CPU);
 // keep the same roundings.
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) posenc_kernel(const T* __restrict__ x, lo
 // [l*C, l*C+C), C = ceil(N/64).  The transmittance is the reference's SEQUENTIAL product, sample after sample in
 // float64 and rounded to float32 per element (torch.cumprod on the CPU accumulates in acc_type<float> = double):
 // every lane walks the whole chain with the `keep` factors broadcast lane by lane, so the weights do not depend
-// on the tiling (raymarch_dev.h composite_tile computes the same chain 16 samples at a time).  Then four weighted
+// on the tiling (raymarch_wave.h composite_tile computes the same chain 16 samples at a time).  Then four weighted
 // wave reductions.
 template <int C>
 __device__ __forceinline__ void composite_wave(const float* __restrict__ rgb, const float* __restrict__ sigma,

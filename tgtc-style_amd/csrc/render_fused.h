@@ -13,7 +13,7 @@
 #include "mlp_nerf_chain.h"
 #include "mlp_nerf_mx_chain.h"
 #include "mlp_pack.h"
-#include "raymarch_dev.h"
+#include "raymarch_wave.h"
 
 namespace tgtc {
 

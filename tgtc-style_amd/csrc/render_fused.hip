@@ -13,7 +13,7 @@
 // one workgroup per CU; ray groups are dealt round-robin.
 //
 // Per-tile arithmetic is the code of the per-sample kernels (mlp_nerf_chain.h, mlp_nerf_mx_chain.h,
-// raymarch_dev.h), so the result of a ray does not depend on which wave, workgroup or launch renders it.
+// raymarch_wave.h), so the result of a ray does not depend on which wave, workgroup or launch renders it.
 #include "render_fused.h"
 
 namespace tgtc {

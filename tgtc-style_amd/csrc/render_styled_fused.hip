@@ -14,7 +14,7 @@
 // LDS: the stylised pass needs two bias tables at once (NeRF 16 KiB + concat/style 16 KiB), so the ring gives up one of its
 // eight 16 KiB slots: 7 x 16 + 16 + 16 + 8 x 1.9 KiB of strips = 159.25 KiB.
 //
-// Per-tile arithmetic is the code of the per-sample kernels (mlp_nerf_chain.h, mlp_style_chain.h, raymarch_dev.h): a ray's
+// Per-tile arithmetic is the code of the per-sample kernels (mlp_nerf_chain.h, mlp_style_chain.h, raymarch_wave.h): a ray's
 // result does not depend on the wave, workgroup or launch that renders it, and equals the chain's to rounding.
 #include "render_fused.h"
 #include "mlp_style_chain.h"
