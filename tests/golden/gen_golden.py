@@ -573,9 +573,69 @@ def g13_files():
         print("files/%-22s %8.1f KB" % (name, os.path.getsize(os.path.join(out_dir, name)) / 1024))
 
 
+# ----------------------------------------------------------------------------- G14 training step
+def g14_train():
+    """One iteration of the reference's `Origin_train` body (train_tgtcs.py:226-254) and the coherence term of `Style_train`
+    (train_tgtcs.py:394-403, :451-458 with VGGNet.py:204-210 and utils.py L2_norm), run through the REFERENCE's own functions
+    with autograd: losses, composited colours and the gradients of all 2 x 24 parameters.
+
+    The body draws three random tensors from torch's global generator -- the stratified jitter inside sampling_pts_uniform
+    (utils.py:519-520) and the density noise inside each alpha_composition (utils.py:371-374).  They are reproduced here by
+    drawing the same three tensors, in the same order, from the same seed, and stored as inputs."""
+    import VGGNet as ref_vggnet
+    R, N, NF, std = 96, 32, 32, 1.0
+    ro, rd = test_rays(R, 1414)
+    rng = np.random.default_rng(1415)
+    gt = rng.uniform(0, 1, (R, 3)).astype(np.float32)
+
+    class A(Args):
+        N_samples, N_samples_fine, sigma_noise_std = N, NF, std
+    model, model_fine = make_nerf(0, "coarse", A).train(), make_nerf(1, "fine", A).train()
+    seed = 141414
+    torch.manual_seed(seed)
+    jit = torch.zeros(R, N)
+    torch.nn.init.uniform_(jit, 0, 1)
+    noise_c = torch.randn(R, N) * std
+    noise_f = torch.randn(R, N + NF) * std
+    torch.manual_seed(seed)                                   # the body itself, as train() runs it
+    rays_o, rays_d, rgb_gt = torch.from_numpy(ro), torch.from_numpy(rd), torch.from_numpy(gt)
+    pts, ts = ref_utils.sampling_pts_uniform(rays_o=rays_o, rays_d=rays_d, N_samples=N, near=0., far=1., perturb=True)
+    ret = model(pts=pts, dirs=rays_d.unsqueeze(1).expand([R, N, 3]))
+    rgb_exp, t_exp, weights = ref_utils.alpha_composition(ret['rgb'], ret['sigma'], ts, std)
+    loss_rgb = ref_utils.img2mse(rgb_gt, rgb_exp)
+    pts_fine, ts_fine = ref_utils.sampling_pts_fine_torch(rays_o, rays_d, ts, weights, NF)
+    ret_f = model_fine(pts=pts_fine, dirs=rays_d.unsqueeze(1).expand([R, N + NF, 3]))
+    rgb_exp_fine, _, _ = ref_utils.alpha_composition(ret_f['rgb'], ret_f['sigma'], ts_fine, std)
+    loss_rgb_fine = ref_utils.img2mse(rgb_gt, rgb_exp_fine)
+    loss = loss_rgb + loss_rgb_fine
+    loss.backward()
+    out = dict(rays_o=ro, rays_d=rd, rgb_gt=gt, jitter=jit, noise_coarse=noise_c, noise_fine=noise_f, n_coarse=N, n_fine=NF,
+               sigma_noise_std=std, seeds=np.array([0, 1]), ts=ts, ts_fine=ts_fine, rgb_exp=rgb_exp, rgb_exp_fine=rgb_exp_fine,
+               loss_rgb=loss_rgb, loss_rgb_fine=loss_rgb_fine, loss=loss)
+    for tag, m in (("coarse", model), ("fine", model_fine)):
+        for k, p in m.state_dict(keep_vars=True).items():
+            out["grad_%s.%s" % (tag, k)] = p.grad
+    # the coherence term: two consecutive frame-ordered batches of R2 rays (cnt = 1: neither the first batch nor a restart)
+    R2 = 64
+    x_prev = torch.from_numpy(rng.uniform(0, 1, (R2, 3)).astype(np.float32))            # rgb_exp_style2 of the previous batch
+    y_prev = torch.from_numpy(rng.uniform(0, 1, (R2, 3)).astype(np.float32))            # rgb_exp_style_fine2 of the previous batch
+    xo_prev = torch.from_numpy(rng.uniform(0, 1, (R2, 3)).astype(np.float32))           # rgb_origin2 of the previous batch
+    rgb2 = torch.from_numpy(rng.uniform(0, 1, (R2, 3)).astype(np.float32)).requires_grad_()
+    rgb_fine2 = torch.from_numpy(rng.uniform(0, 1, (R2, 3)).astype(np.float32)).requires_grad_()
+    rgb_origin2 = torch.from_numpy(rng.uniform(0, 1, (R2, 3)).astype(np.float32))
+    loss_coh = ref_utils.L2_norm(ref_vggnet.cosine_similarity(rgb2, x_prev) - ref_vggnet.cosine_similarity(rgb_origin2, xo_prev))
+    x_origin = rgb_origin2                                                              # :402-403 run before the fine term
+    loss_coh = loss_coh + ref_utils.L2_norm(ref_vggnet.cosine_similarity(rgb_fine2, y_prev)
+                                            - ref_vggnet.cosine_similarity(rgb_origin2, x_origin))
+    loss_coh.backward()
+    out.update(coh_x_prev=x_prev, coh_y_prev=y_prev, coh_x_origin_prev=xo_prev, coh_rgb2=rgb2, coh_rgb_fine2=rgb_fine2,
+               coh_rgb_origin2=rgb_origin2, coh_loss=loss_coh, coh_grad_rgb2=rgb2.grad, coh_grad_rgb_fine2=rgb_fine2.grad)
+    save("g14_train", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_rays, g2_coarse, g3_embed, g4_nerf, g5_composite, g6_fine, g7_style, g8_end_to_end, g9_style2d, g10_image,
-               g11_llff_poses, g12_vae, g13_files):
+               g11_llff_poses, g12_vae, g13_files, g14_train):
         if not only or fn.__name__.split("_")[0] in only:
             fn()

@@ -171,6 +171,54 @@ def test_fused_training_path_matches_the_unfused_one():
             assert float(db.abs().max()) <= 3e-5 * sb, (M, l, "bias", float(db.abs().max()) / sb, S[:10].tolist())
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_origin_train_step_matches_the_reference_golden(golden, fused):
+    """g14 (tests/golden/gen_golden.py g14_train) = one Origin_train iteration run by the REFERENCE's own code and autograd
+    (train_tgtcs.py:226-254) with its three random draws recorded.  The HIP training path on the same inputs: the two
+    losses, the composited colours and all 2 x 24 parameter gradients against the reference's, under the rule of the oracle
+    test above: max(2e-5, 3 x what float32 autograd itself is away from float64) relative to the tensor maximum."""
+    import test_oracle_golden as og
+    from tgtc_style_amd import models, utils
+    g = golden("g14_train")
+    R, N, NF = g["rays_o"].shape[0], int(g["n_coarse"]), int(g["n_fine"])
+    ro, rd = torch.from_numpy(g["rays_o"]).cuda(), torch.from_numpy(g["rays_d"]).cuda()
+    gt = torch.from_numpy(g["rgb_gt"]).cuda()
+    nets = []
+    for seed, mode in zip(g["seeds"], ("coarse", "fine")):
+        m = models.StyleNerf(Args, mode=mode)
+        m.load_state_dict(T(synth.nerf_state(int(seed))))
+        nets.append(m.cuda().trainable(fused=fused))
+    pts, ts = utils.sampling_pts_uniform(ro, rd, N_samples=N, near=0., far=1., jitter=torch.from_numpy(g["jitter"]).cuda())
+    ret = nets[0](pts=pts, dirs=rd[:, None, :].expand(R, N, 3))
+    rgb_c, _, w_c = utils.alpha_composition(ret["rgb"], ret["sigma"], ts, noise=torch.from_numpy(g["noise_coarse"]).cuda())
+    pts_f, ts_f = utils.sampling_pts_fine_torch(ro, rd, ts, w_c.detach(), NF)
+    ret = nets[1](pts=pts_f, dirs=rd[:, None, :].expand(R, N + NF, 3))
+    rgb_f, _, _ = utils.alpha_composition(ret["rgb"], ret["sigma"], ts_f, noise=torch.from_numpy(g["noise_fine"]).cuda())
+    l_c, l_f = ((rgb_c - gt) ** 2).mean(), ((rgb_f - gt) ** 2).mean()
+    (l_c + l_f).backward()
+    assert float((ts.cpu() - torch.from_numpy(g["ts"])).abs().max()) <= 1e-7
+    assert float((ts_f.cpu() - torch.from_numpy(g["ts_fine"])).abs().max()) <= 2e-5
+    assert float((rgb_c.detach().cpu() - torch.from_numpy(g["rgb_exp"])).abs().max()) <= 2e-5
+    assert float((rgb_f.detach().cpu() - torch.from_numpy(g["rgb_exp_fine"])).abs().max()) <= 2e-5
+    assert abs(float(l_c.detach()) - float(g["loss_rgb"])) <= 1e-5 * float(g["loss_rgb"])
+    assert abs(float(l_f.detach()) - float(g["loss_rgb_fine"])) <= 1e-5 * float(g["loss_rgb_fine"])
+    o64 = og._oracle_train_step(g, torch.float64)          # the yardstick: how far the reference's float32 autograd is from float64
+    worst, bad = 0.0, []
+    for tag, m, g64 in zip(("coarse", "fine"), nets, o64["grads"]):
+        for k, p in m.state_dict(keep_vars=True).items():
+            ref = torch.from_numpy(g["grad_%s.%s" % (tag, k)]).double()
+            scale = float(ref.abs().max()) + 1e-30
+            err = float((p.grad.double().cpu() - ref).abs().max()) / scale
+            yard = float((g64[k].double() - ref).abs().max()) / scale
+            worst = max(worst, err)
+            if err > max(2e-5, 3 * yard):
+                bad.append((tag, k, err, yard))
+    print("HIP (%s) vs the reference's own autograd: worst relative gradient difference %.2e" % ("fused" if fused else "per layer", worst))
+    assert not bad, bad
+    if fused:
+        assert nets[0].training_overflows() == 0 and nets[1].training_overflows() == 0
+
+
 def test_two_forwards_before_one_backward_keep_their_own_stash():
     """the reference's Origin_train calls the net through utils.batchify (utils.py:435-456), i.e. TWO forwards of
     32 768 samples before ONE backward; the fused path's activation stash must belong to the call, not to the trainer.  The
