@@ -493,7 +493,7 @@ def main():
                          mfma_pipe_frac=alt["roofline"]["mfma_pipe_frac"], note=NOTES.get(p, ""))
             line.setdefault("alt_precisions", []).append(entry)
         if world == 1:
-            short = max(2, min(args.steps, 3))
+            short = int(os.environ.get("TGTC_BENCH_CONFIG_STEPS", max(2, min(args.steps, 3))))   # (profiling runs vary it)
             cfg = {}
             wanted = [c for c in args.configs.split(",") if c]
             if "styled" in wanted:      # BASELINE config 3, ray path: the stylised chain (NeRF + concat MLP + style MLP)

@@ -207,8 +207,10 @@ def test_g12_vae_encode(golden):
     vae.load_state_dict(T(synth.vae_state(9)))          # strict
 
 
-def _oracle_train_step(g, dtype):
-    """The oracle's formulas for the Origin_train body (train_tgtcs.py:226-254) with autograd, on g14's stored inputs."""
+def _oracle_train_step(g, dtype, golden_depths=False):
+    """The oracle's formulas for the Origin_train body (train_tgtcs.py:226-254) with autograd, on g14's stored inputs.
+    golden_depths: evaluate the fine half at the fine depths the reference sampled (the sampler is not differentiated, and a
+    chain in another precision may take another branch of it on an ill-conditioned ray)."""
     R, N, NF = g["rays_o"].shape[0], int(g["n_coarse"]), int(g["n_fine"])
     ro, rd, gt = tt(g["rays_o"]), tt(g["rays_d"]), tt(g["rgb_gt"]).to(dtype)
     w = [{k: v.clone().to(dtype).requires_grad_() for k, v in T(synth.nerf_state(int(s))).items()} for s in g["seeds"]]
@@ -222,6 +224,9 @@ def _oracle_train_step(g, dtype):
     rgb, sig = net(w[0], pts, N)
     rgb_c, _, w_c = raymarch.composite(rgb, sig + tt(g["noise_coarse"]).to(dtype), ts.to(dtype))
     pts_f, ts_f = raymarch.sample_fine(ro, rd, ts, w_c.detach().float(), NF)      # the sampler carries no gradient (utils.py:562-579)
+    if golden_depths:
+        ts_f = tt(g["ts_fine"])
+        pts_f = ro[:, None, :] + rd[:, None, :] * ts_f[..., None]
     rgb, sig = net(w[1], pts_f, N + NF)
     rgb_f, _, _ = raymarch.composite(rgb, sig + tt(g["noise_fine"]).to(dtype), ts_f.to(dtype))
     l_c, l_f = ((rgb_c - gt) ** 2).mean(), ((rgb_f - gt) ** 2).mean()

@@ -174,6 +174,7 @@ struct SingleStreamMap {
 #endif
 template <class C, class Map, bool PERSIST = false, bool ASM_DMA = kAsmDmaDefault>
 struct WeightStream {
+    static constexpr bool IS_PERSIST = PERSIST;
     static constexpr int NFRAG = Map::NFRAG;
     static constexpr int NCHUNK = (NFRAG + C::FPC - 1) / C::FPC;
     static constexpr int PADC = PERSIST ? (NCHUNK + C::SLOTS - 1) / C::SLOTS * C::SLOTS : NCHUNK;

@@ -5,8 +5,17 @@
 #pragma once
 #include "mlp_layouts.h"
 #include "mlp_mx.h"
+#include "mx_asm.h"
+
+// 1: in the persistent (fused ray kernel) FULL pass the 256 -> 256 layers 1-4, 6-7 and 9 run as the generated instruction
+// streams of tools/gen_mx_asm.py (mx_asm_nerf.inc; bit-identical to dense_mx, profiles/r4_kernel_variants.md)
+#ifndef TGTC_MX_ASM
+#define TGTC_MX_ASM 1
+#endif
 
 namespace tgtc {
+
+#include "mx_asm_nerf.inc"
 
 constexpr int mx_bytes_upto(const MxTable& t, int nq) {
     const int end = t.off[nq - 1] + (t.npe[nq - 1] ? t.npe[nq - 1] * 2048 : kMxKGroupBytes);
@@ -29,15 +38,27 @@ __device__ __forceinline__ void nerf_chain_mx(Reader& rd, lds_cptr bias_lane, ld
     auto to_Y = [&](auto rt_, auto h_, const float4v& acc) { mx_store_act<decltype(rt_)::value, decltype(h_)::value>(acc, Y, l16); };
     auto to_X = [&](auto rt_, auto h_, const float4v& acc) { mx_store_act<decltype(rt_)::value, decltype(h_)::value>(acc, X, l16); };
 
+    // the generated streams hand over a DEPTH-1 persistent reader with 16 KiB chunks (tools/gen_mx_asm.py); every other
+    // reader (the per-sample kernel's draining ring, development depths) keeps the HIP loop
+    constexpr bool ASM = TGTC_MX_ASM && FULL && Reader::Ring::IS_PERSIST && Reader::DEPTH == 1 && Reader::Ring::STAG == 0 &&
+                         kChunkBytes == 16384 && C::SLOTS == 8;
     dense_mx<C, T.first[0], NQ, 16, 0, 2, L::bias0(0)>(rd, bias_lane, rs_lane, none, Ph, Pl, to_Y);
-    dense_mx<C, T.first[1], NQ, 16, 2, 0, L::bias0(1)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
-    dense_mx<C, T.first[2], NQ, 16, 2, 0, L::bias0(2)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
-    dense_mx<C, T.first[3], NQ, 16, 2, 0, L::bias0(3)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
-    dense_mx<C, T.first[4], NQ, 16, 2, 0, L::bias0(4)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
+    if constexpr (ASM) {
+        mx_asm_nerf_full_l1_4(rd, bias_lane, rs_lane, Y, Y);
+    } else {
+        dense_mx<C, T.first[1], NQ, 16, 2, 0, L::bias0(1)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
+        dense_mx<C, T.first[2], NQ, 16, 2, 0, L::bias0(2)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
+        dense_mx<C, T.first[3], NQ, 16, 2, 0, L::bias0(3)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
+        dense_mx<C, T.first[4], NQ, 16, 2, 0, L::bias0(4)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
+    }
     // skip layer: reference input is cat(pe, h) (models.py:98-99); k order here is [h | pe]
     dense_mx<C, T.first[5], NQ, 16, 2, 2, L::bias0(5)>(rd, bias_lane, rs_lane, Y, Ph, Pl, to_X);
-    dense_mx<C, T.first[6], NQ, 16, 2, 0, L::bias0(6)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
-    dense_mx<C, T.first[7], NQ, 16, 2, 0, L::bias0(7)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
+    if constexpr (ASM) {
+        mx_asm_nerf_full_l6_7(rd, bias_lane, rs_lane, X, X);
+    } else {
+        dense_mx<C, T.first[6], NQ, 16, 2, 0, L::bias0(6)>(rd, bias_lane, rs_lane, X, nop, nop, to_Y);
+        dense_mx<C, T.first[7], NQ, 16, 2, 0, L::bias0(7)>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
+    }
 
     // sigma head (models.py:103): row 0 of a 16-row tile -> lanes 0..15, register 0
     dense_mx<C, T.first[8], NQ, 1, 2, 0, L::bias0(8)>(rd, bias_lane, rs_lane, X, nop, nop, [&](auto, auto h_, const float4v& acc) {
