@@ -131,6 +131,14 @@ struct MlpCfg {
 // pipe never drains at a boundary.
 typedef __attribute__((address_space(3))) const char* lds_cptr;
 
+// The lane id, re-read from the hardware where it is called: `threadIdx.x & 63` (and any pure function of it) is computed
+// once per kernel by hipcc and kept -- or spilled -- from there on; a volatile asm is evaluated in place.
+__device__ __forceinline__ int fresh_lane_id() {
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    return lane;
+}
+
 __device__ __forceinline__ lds_cptr opaque(lds_cptr p) {
     // hide the constant relation between LDS base registers from the optimiser, so that every
     // fragment read is `ds_read_b128 v, base offset:imm16` (no per-read address arithmetic)
@@ -542,7 +550,11 @@ __device__ __forceinline__ void sincos_turns(double turns, float& s, float& c) {
     if constexpr (ACCURATE) {
         const double t = turns * 4.0;
         const double n = rint(t);
-        const float a = (float)(t - n) * 1.57079632679489661923f;  // [-pi/4, pi/4]
+        // (the constant is materialised here: as a plain literal hipcc pairs it into a v_pk_mul_f32 operand that it keeps in
+        // a register for the whole kernel -- and spills and reloads around the asm blocks of the fp16mx pass)
+        float half_pi = 1.57079632679489661923f;
+        asm volatile("" : "+v"(half_pi));
+        const float a = (float)(t - n) * half_pi;  // [-pi/4, pi/4]
         const float a2 = a * a;
         const float sp = a + a * a2 * (-1.6666654611e-1f + a2 * (8.3321608736e-3f + a2 * (-1.9515295891e-4f)));
         const float cp = 1.0f - 0.5f * a2 +

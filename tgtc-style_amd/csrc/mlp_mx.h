@@ -118,6 +118,17 @@ struct MxReader {
         b8_lo = opaque((lds_cptr)smem + lane * 8);
         b8_hi = opaque((lds_cptr)smem + (C::RING_BYTES > 65536 ? 65536 : 0) + lane * 8);
     }
+    // Re-derive every per-lane address of the reader from a freshly read lane id (around the generated asm blocks of
+    // mx_asm_nerf.inc: values that are live across such a block are spilled by hipcc -- the block clobbers v40..v251 -- and
+    // a scratch reload waits vmcnt(0), i.e. for the ring's whole look-ahead; values that die in front of it are not)
+    __device__ __forceinline__ void relane(char* smem, int wave) {
+        const int lane = fresh_lane_id();
+        ring.voff = wave * (C::GPC * 1024) + lane * 16;
+        ring.lane_lo = opaque((lds_cptr)smem + lane * 16);
+        ring.lane_hi = opaque((lds_cptr)smem + (C::RING_BYTES > 65536 ? 65536 : 0) + lane * 16);
+        b8_lo = opaque((lds_cptr)smem + lane * 8);
+        b8_hi = opaque((lds_cptr)smem + (C::RING_BYTES > 65536 ? 65536 : 0) + lane * 8);
+    }
     template <int OFF>
     __device__ __forceinline__ half8 read16() const {
         constexpr int o = OFF % C::RING_BYTES;

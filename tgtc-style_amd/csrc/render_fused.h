@@ -94,14 +94,16 @@ __device__ __forceinline__ void fused_pass(char* smem, int wave, int lane, const
     if constexpr (PREC == TGTC_PREC_FP16_FP6) {
         constexpr int NQ = nerf_mx_groups(FULL);
         const lds_cptr rs_lane = opaque((lds_cptr)smem + C::RING_BYTES + kNerfMxScaleOff + 2 * n);
+        if constexpr (TGTC_MX_ASM && FULL) st.relane(smem, wave);   // (per-lane addresses from a lane id read HERE: see MxReader::relane)
         st.ring.next = st.ring.src[0];   // the stream this pass enters (its first chunks are in flight) ...
         st.template enter<0, NQ>();
         st.ring.next = next_src;         // ... and the one its look-ahead runs into
         const half8 Ph[2] = {pe_h[0][0], pe_h[1][0]}, Pl[2] = {pe_l[0][0], pe_l[1][0]};
         nerf_chain_mx<C, FULL>(
-            st, bias_lane, rs_lane, Ph, Pl, [&](half8& dh, half8& dl) { encode_dir<true, true>(d, g, dh, dl, nullptr); },
+            st, bias_lane, rs_lane, Ph, Pl,
+            [&](half8& dh, half8& dl) { encode_dir<true, true>(d, g, dh, dl, nullptr); },
             [&](float s) { sig[0] = s; }, [](auto, auto, const float4v&) {},
-            [&](auto h_, const float4v& acc) { colour(ic<0>{}, h_, acc); });
+            [&](auto h_, const float4v& acc) { colour(ic<0>{}, h_, acc); }, smem, wave);
         st.template finish<NQ>();
     } else {
         st.next = st.src[0];

@@ -29,19 +29,15 @@ __global__ void __launch_bounds__(512, 2) fused_render_kernel(FusedArgs a) {
     // ring | bias table of the running phase (+ row exponents) | per-wave strips
     __shared__ __attribute__((aligned(16))) char smem[CC::RING_BYTES + kNerfBiasBytes + NW * kFusedStripBytes];
 
-    // `lane` is re-derived (fresh_lane) wherever per-lane addresses are formed inside the ray loop: values the optimiser
-    // can hoist out of that loop stay live across the passes and are spilled (see fused_pass)
-    const int lane = threadIdx.x & 63;
+    // The lane id is re-read from the hardware (fresh_lane_id, mlp_core.h) wherever per-lane addresses are formed: a kernel-long
+    // `threadIdx.x & 63` -- and whatever the optimiser hoists out of the ray loop -- stays live across the passes and is
+    // spilled (see fused_pass), or evicted and restored around the asm blocks of the fp16mx pass (mx_asm_nerf.inc)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef TGTC_FUSED_PRIO
     // experiment (CDNA guide T5, static form): the younger half of an 8-wave workgroup loses VALU arbitration on every segment
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
-    auto fresh_lane = [&] {
-        int l = lane;
-        asm volatile("" : "+v"(l));
-        return l;
-    };
+    auto fresh_lane = [&] { return fresh_lane_id(); };
     auto strip = [&]() -> float* {
         return reinterpret_cast<float*>(smem + CC::RING_BYTES + kNerfBiasBytes + wave * kFusedStripBytes);
     };
@@ -52,7 +48,7 @@ __global__ void __launch_bounds__(512, 2) fused_render_kernel(FusedArgs a) {
 #pragma unroll
         for (int j = 0; j < kNerfBiasBytes / (NW * 1024); ++j)
             lds_dma16_t<(PC == TGTC_PREC_FP16_FP6 || PF == TGTC_PREC_FP16_FP6)>(
-                net + (j * NW + wave) * 1024 + lane * 16, smem + CC::RING_BYTES + (j * NW + wave) * 1024);
+                net + (j * NW + wave) * 1024 + fresh_lane() * 16, smem + CC::RING_BYTES + (j * NW + wave) * 1024);
         wait_vmcnt<0>();
     };
     // the compositing state lives in the strip between passes (all lanes hold the same values)
@@ -78,7 +74,7 @@ __global__ void __launch_bounds__(512, 2) fused_render_kernel(FusedArgs a) {
     {   // chunks 0 .. SLOTS-2 of the first coarse pass: the state every enter() expects
         typename FusedStream<PC, false>::type first;
         const char* const one[1] = {a.net_c + kNerfBiasBytes};
-        first.init(one, smem, wave, lane);
+        first.init(one, smem, wave, fresh_lane());
         if constexpr (PC == TGTC_PREC_FP16_FP6) {
             first.ring.next = first.ring.src[0];
             first.ring.persist_prologue();
@@ -126,7 +122,7 @@ __global__ void __launch_bounds__(512, 2) fused_render_kernel(FusedArgs a) {
             wave_sync();
             depths(tt, tn);
             const bool last = tile + CC::NCT >= tiles_c;
-            fused_pass<PC, false>(smem, wave, lane, a.net_c, ((last && !DEPTHS) ? a.net_f : a.net_c) + kNerfBiasBytes, o, d, tt, sig, col);
+            fused_pass<PC, false>(smem, wave, fresh_lane(), a.net_c, ((last && !DEPTHS) ? a.net_f : a.net_c) + kNerfBiasBytes, o, d, tt, sig, col);
             depths(tt, tn);   // recomputed rather than kept across the pass
             RayAccum acc = get_acc();
             float w[CC::NCT];
@@ -171,7 +167,7 @@ __global__ void __launch_bounds__(512, 2) fused_render_kernel(FusedArgs a) {
             float tt[CF::NCT], tn[CF::NCT], sig[CF::NCT], col[CF::NCT][3];
             depths(tt, tn);
             const bool last = tile + CF::NCT >= tiles_f;
-            fused_pass<PF, true>(smem, wave, lane, a.net_f, (last ? a.net_c : a.net_f) + kNerfBiasBytes, o, d, tt, sig, col);
+            fused_pass<PF, true>(smem, wave, fresh_lane(), a.net_f, (last ? a.net_c : a.net_f) + kNerfBiasBytes, o, d, tt, sig, col);
             depths(tt, tn);
             RayAccum acc = get_acc();
             const int n = fresh_lane() & 15;

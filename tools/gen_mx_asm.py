@@ -363,7 +363,10 @@ def emit_block(name, table, q0, nlayers, bias0, nq_pass, units_pass, cfg, out):
         name, q0, q0 + 32 * nlayers, nlayers, bias0, len(lines), n_mfma,
         ", ".join("%s %d" % kv for kv in sorted(stats.items(), key=lambda kv: -kv[1])[:12])))
     out.append("template <class Reader>")
-    out.append("__device__ __forceinline__ void mx_asm_%s(Reader& rd, lds_cptr bias_lane, lds_cptr rs_lane, const MxAct<2>& X, MxAct<2>& Y) {" % name)
+    out.append("// keep[0..5]: 24 registers of the caller (the encodings' hi / lo k-steps in the NeRF chain) pinned to v16..v39")
+    out.append("// across the block: as plain live values hipcc spills them around the block's clobber list, and a scratch reload waits vmcnt(0),")
+    out.append("// i.e. for the whole look-ahead of the ring")
+    out.append("__device__ __forceinline__ void mx_asm_%s(Reader& rd, lds_cptr bias_lane, lds_cptr rs_lane, const MxAct<2>& X, MxAct<2>& Y, half8 (&keep)[6]) {" % name)
     out.append("    static_assert(Reader::DEPTH == 1 && Reader::Ring::STAG == 0, \"the asm streams hand over a DEPTH-1 reader\");")
     out.append("    MxAsmRegs r;")
     out.append("    mx_asm_load(r, X, rd);")
@@ -382,6 +385,7 @@ def emit_block(name, table, q0, nlayers, bias0, nq_pass, units_pass, cfg, out):
         outs += ['"=%s"(%s)' % (rg(base - a + b, n), nm.replace("r.", "y.")) for nm, base, n in xs]
     outs += ['"+%s"(%s)' % (rg(base, n), nm) for nm, base, n in xs]
     outs += ['"+%s"(r.wu)' % rg(R.W0, 16), '"+%s"(r.wl)' % rg(R.W0 + 16, 6), '"+%s"(r.wh)' % rg(R.W0 + 22, 6)]
+    outs += ['"+%s"(keep[%d])' % (rg(16 + 4 * i, 4), i) for i in range(6)]
     out.append("    asm volatile(")
     out.append(block_text(lines))
     ins = ['[lane_lo] "v"(rd.ring.lane_lo)', '[lane_hi] "v"(rd.ring.lane_hi)', '[b8_lo] "v"(rd.b8_lo)', '[b8_hi] "v"(rd.b8_hi)',

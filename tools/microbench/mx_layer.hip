@@ -81,8 +81,9 @@ __global__ void __launch_bounds__(512, 2) k(const char* stream, const char* bias
                 dense_mx<C, kBenchTable.first[2 * i + 1], kNQ, 16, 2, 0, 512 * i + 256>(rd, bias_lane, rs_lane, Y, nop, nop, to_X);
             });
         } else {
-            mx_asm_bench_a(rd, bias_lane, rs_lane, X, Y);
-            mx_asm_bench_b(rd, bias_lane, rs_lane, Y, X);
+            half8 keep[6] = {};
+            mx_asm_bench_a(rd, bias_lane, rs_lane, X, Y, keep);
+            mx_asm_bench_b(rd, bias_lane, rs_lane, Y, X, keep);
         }
         rd.template finish<kNQ>();
 #pragma unroll
