@@ -50,7 +50,6 @@ typedef struct {
 } tgtc_linear;
 
 int tgtc_version(void);
-int tgtc_dev_kernels(void); /* 1: built by `make dev` with the development kernels (not the product library), else 0 */
 const char* tgtc_last_error(void);
 
 /* ------------------------------------------------------------------ a1+a2: ray generation

@@ -246,31 +246,3 @@ def test_render_full_size_properties(precision):
     idx = torch.arange(0, 40 * W, 40 * W // 256)[:256]
     ref = fields.render_plain(T(synth.nerf_state(0)), T(synth.nerf_state(1)), ro[idx].cpu(), rd[idx].cpu(), 128, 64)
     assert float((a["rgb"][idx].cpu() - ref["rgb_fine"]).abs().max()) <= 1e-3
-
-
-@pytest.mark.parametrize("M", [1, 31, 32, 33, 127, 128, 129, 1000, 4096])
-def test_nerf_wide_kernel(M, monkeypatch):
-    """The 32x32x16 ("wide", mlp_wide.h) fp16x3 kernel, a development configuration selected by TGTC_NERF_WIDE=1:
-    tgtc_nerf_forward without the encoding outputs; sample counts around its 32-sample wave tile and 128-sample
-    workgroup."""
-    from tgtc_style_amd import hip
-    lib = hip.load()
-    if not lib.tgtc_dev_kernels():
-        pytest.skip("development kernels are built by `make dev` only (TGTC_LIB=.../libtgtc_hip_dev.so)")
-    monkeypatch.setenv("TGTC_NERF_WIDE", "1")
-    rng = np.random.default_rng(100 + M)
-    pts = torch.from_numpy(rng.uniform(-1.2, 1.2, (M, 3)))
-    dirs = torch.from_numpy(rng.uniform(-1, 1, (M, 3)))
-    sd = synth.nerf_state(1)
-    ref = fields.style_nerf(T(sd), pts, dirs)
-    net = hip.nerf_create({k: torch.from_numpy(v) for k, v in sd.items()}, "fp16x3")
-    p, d = pts.cuda(), dirs.cuda()
-    rgb = torch.full((M, 3), float("nan"), device="cuda")
-    sigma = torch.full((M,), float("nan"), device="cuda")
-    remap = torch.full((M, 256), float("nan"), device="cuda")
-    hip.check(lib.tgtc_nerf_forward(net.handle, hip.ptr(p), hip.ptr(d), M, hip.ptr(rgb), hip.ptr(sigma), hip.ptr(remap),
-                                    None, None, hip.stream()))
-    errs = {"sigma": rel(sigma, ref["sigma"]), "rgb": rel(rgb, ref["rgb"]), "remap": rel(remap, ref["base_remap"])}
-    print(M, errs)
-    for k, e in errs.items():
-        assert e <= TIGHT["fp16x3"] * 2, (k, e)

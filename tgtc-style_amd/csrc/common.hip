@@ -18,12 +18,4 @@ int fail(int code, const char* fmt, ...) {
 }  // namespace tgtc
 
 extern "C" int tgtc_version(void) { return 100; /* 0.1.0 */ }
-// 1 in libtgtc_hip_dev.so (`make dev`: the 32x32x16 "wide" development kernels are compiled in), 0 in the product library
-extern "C" int tgtc_dev_kernels(void) {
-#ifdef TGTC_DEV_KERNELS
-    return 1;
-#else
-    return 0;
-#endif
-}
 extern "C" const char* tgtc_last_error(void) { return tgtc::err_buf(); }

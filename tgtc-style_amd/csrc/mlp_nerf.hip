@@ -258,19 +258,6 @@ TGTC_NERF_FP16_INSTANCES()
 TGTC_NERF_FP16_INSTANCES(extern)
 #endif
 
-#ifdef TGTC_DEV_KERNELS   // `make dev` only (libtgtc_hip_dev.so): development kernels are not part of the product library
-// mlp_nerf_wide.hip
-int nerf_wide_pack(const tgtc_linear* layers, bool split, std::vector<char>& out);
-int nerf_wide_launch(const tgtc_net* net, int in_mode, bool full, NerfArgs a, hipStream_t st);
-
-// The wide (32x32x16, one wave per SIMD) kernels are a development configuration: measured 6 % slower than the
-// 16x16x32 kernels (profiles/r2_kernel_variants.md section 5), results identical to 1e-6.  TGTC_NERF_WIDE=1 selects them.
-static bool wide_selected() {
-    const char* e = std::getenv("TGTC_NERF_WIDE");
-    return e && e[0] == '1';
-}
-#endif
-
 template <int IN_MODE, bool FULL>
 static int dispatch_nerf(const tgtc_net* net, NerfArgs& a, hipStream_t st) {
     a.bias = net->dev;
@@ -287,10 +274,6 @@ static int dispatch_nerf(const tgtc_net* net, NerfArgs& a, hipStream_t st) {
         return nerf_mx_launch(IN_MODE, FULL, a, st);
     }
     if (net->precision == TGTC_PREC_FP16) return launch_nerf<CfgFast, IN_MODE, FULL>(a, st);
-#ifdef TGTC_DEV_KERNELS
-    if (IN_MODE != IN_ENC && net->wide_off && !a.out_pts_enc && !a.out_dirs_enc && wide_selected())
-        return nerf_wide_launch(net, IN_MODE, FULL, a, st);
-#endif
     return launch_nerf<CfgExact, IN_MODE, FULL>(a, st);
 #endif
 }
@@ -345,13 +328,6 @@ extern "C" int tgtc_nerf_create(const tgtc_linear* layers, int n_layers, int pre
                       reinterpret_cast<const char*>(p.stream.data()) + p.stream.size() * sizeof(half_t));
         n_frags = p.n_frags;
     }
-    std::vector<char> wide;
-#ifdef TGTC_DEV_KERNELS
-    if (precision == TGTC_PREC_FP16X3) {
-        const int rc = nerf_wide_pack(layers, true, wide);
-        if (rc != TGTC_OK) return rc;
-    }
-#endif
     tgtc_net* net = new tgtc_net();
     net->kind = 0, net->precision = precision;
     net->bias_bytes = kNerfBiasBytes;
@@ -360,11 +336,6 @@ extern "C" int tgtc_nerf_create(const tgtc_linear* layers, int n_layers, int pre
     // + one ring of slack: the fused ray kernel rounds a pass up to a whole number of rings and fetches (never reads)
     // the chunks behind the stream's end (mlp_core.h, WeightStream PERSIST)
     size_t total = net->bias_bytes + net->stream_bytes + kRingBytes;
-    if (!wide.empty()) {
-        net->wide_off = (total + 255) & ~(size_t)255;
-        net->wide_stream_bytes = wide.size() - kNerfBiasBytes;
-        total = net->wide_off + wide.size() + kRingBytes;
-    }
     hipError_t e = hipMalloc((void**)&net->dev, total);
     if (e != hipSuccess) {
         delete net;
@@ -373,7 +344,6 @@ extern "C" int tgtc_nerf_create(const tgtc_linear* layers, int n_layers, int pre
     std::vector<char> host(total, 0);
     std::memcpy(host.data(), bias_region.data(), bias_region.size());
     std::memcpy(host.data() + net->bias_bytes, stream.data(), net->stream_bytes);
-    if (!wide.empty()) std::memcpy(host.data() + net->wide_off, wide.data(), wide.size());
     e = hipMemcpy(net->dev, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(net->dev);

@@ -155,49 +155,6 @@ inline PackedNet pack_layers(const std::vector<LayerSpec>& layers, bool split) {
     return p;
 }
 
-// The wide (32x32x16, mlp_wide.h) order of the same data: 32-row tiles, 16-deep k-steps (Seg::ksteps counts those),
-// lane (r = lane&31, h = lane>>5); `col(seg, k, h, j)` maps a k-slot to the logical input column or -1.
-// The bias table holds 32 floats per row tile in the accumulator's register order [h][q]: row 8*(q>>2) + 4h + (q&3).
-template <class ColFn>
-inline PackedNet pack_layers_w(const std::vector<LayerSpec>& layers, bool split, ColFn&& col) {
-    PackedNet p;
-    const int frag_halves = kFragHalves * (split ? 2 : 1);
-    for (const LayerSpec& L : layers) {
-        p.frag0.push_back(p.n_frags);
-        p.bias0.push_back((int)p.bias.size());
-        const int RT = (L.out + 31) / 32;
-        for (int rt = 0; rt < RT; ++rt) {
-            for (int h = 0; h < 2; ++h)
-                for (int q = 0; q < 16; ++q) {
-                    const int row = 32 * rt + 8 * (q >> 2) + 4 * h + (q & 3);
-                    p.bias.push_back(row < L.out ? L.b[row] : 0.0f);
-                }
-            for (const Seg& s : L.segs) {
-                for (int k = 0; k < s.ksteps; ++k) {
-                    const size_t base = p.stream.size();
-                    p.stream.resize(base + frag_halves, (half_t)0.0f);
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int r = lane & 31, h = lane >> 5, row = 32 * rt + r;
-                        for (int j = 0; j < 8; ++j) {
-                            const int c0 = col(s, k, h, j);
-                            const int c = c0 < 0 ? -1 : s.col0 + c0;
-                            float w = 0.0f;
-                            if (row < L.out && c >= 0 && c < L.in) w = L.W[(size_t)row * L.in + c];
-                            const half_t hi = (half_t)w;
-                            p.stream[base + lane * 8 + j] = hi;
-                            if (split) p.stream[base + kFragHalves + lane * 8 + j] = (half_t)(w - (float)hi);
-                        }
-                    }
-                    ++p.n_frags;
-                }
-            }
-        }
-    }
-    const size_t chunk_halves = kChunkBytes / sizeof(half_t);
-    p.stream.resize((p.stream.size() + chunk_halves - 1) / chunk_halves * chunk_halves, (half_t)0.0f);
-    return p;
-}
-
 }  // namespace tgtc
 
 // The opaque handle of the C ABI.
@@ -213,6 +170,4 @@ struct tgtc_net {
     int n_frags2;
     size_t stash_off;  // per-workgroup scratch slabs of the fused stylised kernel
     int n_wg;          // persistent grid size (= CUs)
-    // NeRF handles of the parity precisions: the same network in the wide (32x32x16) order, [bias 16 KiB][stream][slack]
-    size_t wide_off = 0, wide_stream_bytes = 0;
 };

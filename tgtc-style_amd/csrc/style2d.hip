@@ -524,14 +524,14 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const float* __restri
 // out[row] = LayerNorm(a[row] + b[row]) * w + bias over 512 features; one wavefront per row (eps 1e-5)
 __global__ void __launch_bounds__(256) layernorm512_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
-                                                           float* __restrict__ out, int rows) {
+                                                           float* __restrict__ out, int rows, long long lda) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     float v[8], s = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = lane + 64 * j;
-        v[j] = a[(long long)row * 512 + c] + (b ? b[(long long)row * 512 + c] : 0.0f);
+        v[j] = a[(long long)row * lda + c] + (b ? b[(long long)row * 512 + c] : 0.0f);
         s += v[j];
     }
 #pragma unroll
@@ -928,9 +928,10 @@ static int linear(const tgtc_style2d* h, const float* x, long long ldx, int M, i
     return launch_gemm<DenseRows, false>(h, al, bl, out, M, N, K, 1, st);
 }
 
+// out = LayerNorm(a + b); `lda` = row stride of a (the residual may be a 512-column slice of a wider projection)
 static int layernorm(const float* a, const float* b, const float* w, const float* bias, float* out, int rows,
-                     hipStream_t st) {
-    layernorm512_kernel<<<(rows + 3) / 4, 256, 0, st>>>(a, b, w, bias, out, rows);
+                     hipStream_t st, long long lda = 512) {
+    layernorm512_kernel<<<(rows + 3) / 4, 256, 0, st>>>(a, b, w, bias, out, rows, lda);
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;
 }
@@ -1057,12 +1058,8 @@ static int encoder_layer(const tgtc_style2d* h, const std::string& p, const floa
     if (has_pos) {
         TGTC_TRY(layernorm(src, attn, n1w, n1b, x1, S, st));
     } else {
-        // residual operand is strided (ld 1536): fold the add into a dense copy first
-        float* tmp = ws.take((size_t)S * 512);
-        if (!ws.ok) return fail(TGTC_ERR_ARG, "style2d: workspace too small for an encoder layer (S=%d)", S);
-        TGTC_HIP_CHECK(hipMemcpy2DAsync(tmp, 512 * sizeof(float), val, width * sizeof(float), 512 * sizeof(float), S,
-                                        hipMemcpyDeviceToDevice, st));
-        TGTC_TRY(layernorm(tmp, attn, n1w, n1b, x1, S, st));
+        // the residual operand is the third 512-column chunk of the projection (row stride 1536): read in place
+        TGTC_TRY(layernorm(val, attn, n1w, n1b, x1, S, st, width));
     }
     return ffn_norm(h, p, "norm2", x1, S, ws, out, st);
 }

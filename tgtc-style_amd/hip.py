@@ -33,7 +33,6 @@ class Linear(ctypes.Structure):
 # name -> argtypes (restype is int unless listed in _RESTYPES)
 _SIGNATURES = {
     "tgtc_version": [],
-    "tgtc_dev_kernels": [],
     "tgtc_last_error": [],
     "tgtc_gen_rays": [c_int, c_int, c_double, c_double, c_double, c_double, c_void_p, c_int, c_int, c_double,
                       c_int64, c_int64, c_void_p, c_void_p, c_void_p],
