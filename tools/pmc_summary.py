@@ -26,7 +26,7 @@ for r in sorted(stats, key=lambda r: -float(r.get("TotalDurationNs", r.get("Tota
     print("%9.3f ms avg  x%-4s %6s%%  %s" % (avg / 1e6, calls, pct, short(name)))
 
 # 2/3. counters
-for sub in ("fetch", "write", "sq"):
+for sub in ("fetch", "write", "sq", "sq2"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows(sub + "/**/*counter_collection.csv"):
         acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))

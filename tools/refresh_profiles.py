@@ -7,8 +7,8 @@ corrected one: on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide 
 weight streams -- all but ~8 MB of what the fused ray kernel fetches -- and of the 16-byte-per-lane slab reloads of the
 stylised kernel.  WRITE_SIZE is exact for 16-byte-per-lane stores and is taken as read."""
 import csv, glob, json, os, shutil, subprocess, sys
-top = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof_r3'
-tag = sys.argv[2] if len(sys.argv) > 2 else 'r3'
+top = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof_r4'
+tag = sys.argv[2] if len(sys.argv) > 2 else 'r4'
 
 
 def mean(run, sub, counter, key):
@@ -21,7 +21,7 @@ def mean(run, sub, counter, key):
 
 
 head = subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD']).decode().strip()
-d = {"collected": "tools/profile_r3.sh on MI355X: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of "
+d = {"collected": "tools/profile_%s.sh on MI355X" % tag + ": rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of "
                   "`python3 bench.py --steps 4 --warmup 2 --cpu-rays 0 --alt-precision= --configs=<one> --precision <p>`; means per dispatch; "
                   "summaries profiles/%s_<run>_rocprof_summary.txt" % tag,
      "commit": head,

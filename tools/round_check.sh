@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-of-round check on the GPU box: whole GPU suite, smoke, default bench line, two-rank rehearsals (gloo, both ranks on
-# the one GPU), then the profile passes of tools/profile_r3.sh.  Outputs under gpurun_out/round_check/.
+# the one GPU), then the profile passes of tools/profile_r4.sh.  Outputs under gpurun_out/round_check/.
 set -o pipefail
 O=gpurun_out/round_check; mkdir -p $O
 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1; echo "pytest rc $?" | tee -a $O/status.txt; tail -3 $O/pytest_gpu.txt
@@ -11,4 +11,4 @@ for sh in frames rays; do
       bench.py --gpus 2 --steps 3 --warmup 1 --sharding $sh --cpu-rays 0 --alt-precision "" --configs "" > $O/bench_2rank_$sh.json 2> $O/bench_2rank_$sh.err
   echo "2-rank $sh rc $?" | tee -a $O/status.txt; tail -c 400 $O/bench_2rank_$sh.json; echo
 done
-bash tools/profile_r3.sh > $O/profile.txt 2>&1; echo "profile rc $?" | tee -a $O/status.txt; tail -60 $O/profile.txt
+bash tools/profile_r4.sh > $O/profile.txt 2>&1; echo "profile rc $?" | tee -a $O/status.txt; tail -60 $O/profile.txt
