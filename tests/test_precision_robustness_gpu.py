@@ -89,3 +89,52 @@ def test_headline_precision_on_heavy_tailed_weights(golden):
                                     stages=lambda sel, c=nets[0], o=ro, d=rd: conditioning.hip_stages(c, o[sel.cuda()].contiguous(), d[sel.cuda()].contiguous(), NC, NF))
         worst = max(worst, float(e.max()))
     print("worst case %.2e: margin %.1fx inside 1e-3" % (worst, 1e-3 / worst))
+
+
+@pytest.mark.parametrize("family,k", [("rows", 0), ("rows", 1), ("outliers", 0), ("outliers", 1)])
+def test_stylised_chain_on_heavy_tailed_style_mlps(family, k):
+    """The same question for the stylised chain (VERDICT r3 item 3b asked for the sweep on the style nets): concat MLP and style
+    MLP with per-feature scales spread over 2^12 (synth.heavy_tailed_style: the same function by ReLU's scaling symmetry)
+    through the stylised ray kernel, every ray under the frozen criterion.  The packers equalise these nets like the NeRF ones."""
+    from tgtc_style_amd import models, rendering, utils
+
+    class A(Args):
+        style_D, vae_latent = 8, 32
+    H = W = 400
+    fo, fd = utils.gen_rays(H, W, synth.fern_intrinsics(H, W), synth.spiral_pose(6))
+    idx = torch.linspace(0, H * W - 1, 320).long().cuda()
+    ro, rd = fo[idx].contiguous(), fd[idx].contiguous()
+    raw_c, raw_s = synth.heavy_tailed_style(synth.concat_state(2), synth.style_state(3), 10 * k + 1, family)
+    # the function is the base nets': check that in float64 before trusting the sweep
+    x = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (64, 63)))
+    z = torch.from_numpy(np.random.default_rng(2).standard_normal((64, 32)))
+    cf0 = fields.concat_mlp(T(synth.concat_state(2), torch.float64), x, z)["concat_features"]
+    cf1 = fields.concat_mlp(T(raw_c, torch.float64), x, z)["concat_features"]
+    both = torch.cat([torch.from_numpy(np.random.default_rng(3).uniform(0, 1, (64, 256))), cf0], -1)
+    r0 = fields.style_mlp(T(synth.style_state(3), torch.float64), x, both, z)["rgb"]
+    r1 = fields.style_mlp(T(raw_s, torch.float64), x, torch.cat([both[:, :256], cf1], -1), z)["rgb"]
+    assert float((r0 - r1).abs().max()) <= 1e-9
+    cm, sm = models.StyleMLP_before_concat(A), models.StyleMLP_Wild_multilayers(A)
+    cm.load_state_dict(T(raw_c)), sm.load_state_dict(T(raw_s))
+    nets = []
+    for seed, mode in ((0, "coarse"), (1, "fine")):
+        m = models.StyleNerf(A, mode=mode)
+        m.load_state_dict(T(synth.nerf_state(seed)))
+        nets.append(m.cuda())
+    lat = models.StyleLatents_variational(style_num=1, frame_num=20, latent_dim=32)
+    lat.load_state_dict(T(synth.latents_state(4)))
+    lat = lat.cuda()
+    lat.sigma_scale = 1.0
+    R = ro.shape[0]
+    zz = lat(style_ids=torch.zeros(R, dtype=torch.long), frame_ids=torch.full((R,), 9, dtype=torch.long), type="llff")
+    r = rendering.RayRenderer(nets[0], nets[1], models.StylePair(cm.cuda(), sm.cuda()))
+    assert r._fused_styled_shape(NC, NF)
+    out = r.render(ro, rd, NC, NF, z=zz)
+    zi = zz.cpu()
+    raw = [synth.nerf_state(0), synth.nerf_state(1), raw_c, raw_s]
+
+    def oracle(o, d, dc, df, sel, **kw):
+        w = [T(sd, dc) for sd in raw]
+        return fields.render_styled(w[0], w[1], w[2], w[3], o, d, (zi if sel is None else zi[sel]).to(dc), NC, NF, dtype=dc, **kw)
+    conditioning.check("styled %-8s set %d" % (family, k), out["rgb"].cpu(), out["t"].cpu(), oracle, ro.cpu(), rd.cpu(), tol=1e-3, mixed=False,
+                       n_fine=NF, stages=lambda sel: conditioning.hip_stages(nets[0], ro[sel.cuda()].contiguous(), rd[sel.cuda()].contiguous(), NC, NF))

@@ -102,6 +102,41 @@ def heavy_tailed(sd, seed, family):
     return sd
 
 
+def heavy_tailed_style(concat_sd, style_sd, seed, family):
+    """The stylised chain's two MLPs (StyleMLP_before_concat, StyleMLP_Wild_multilayers) with heavy-tailed numbers: the 'rows' /
+    'outliers' families of `heavy_tailed` applied through the same ReLU scaling symmetry -- row i of a hidden layer and its
+    bias times s_i (a power of two), column i of its consumer times 1/s_i -- so both nets compute the SAME function.  Input
+    layouts (models.py:137-147, :165-180): every layer reads cat(h, latent [, x]) with h in columns 0..255; the style MLP's
+    layer 0 reads cat(base_remap, concat_features, x, latent), the concat MLP's output in columns 256..511."""
+    if family == "base":
+        return concat_sd, style_sd
+    if family not in ("rows", "outliers"):
+        raise ValueError(family)
+    rng = np.random.default_rng(3000 + seed)
+    c = {k: v.copy() for k, v in concat_sd.items()}
+    st = {k: v.copy() for k, v in style_sd.items()}
+
+    def scales(n=256):
+        if family == "rows":
+            return np.exp2(np.rint(rng.normal(0.0, 2.0, n))).astype(np.float32)
+        s = np.ones(n, np.float32)
+        idx = rng.choice(n, 6, replace=False)
+        s[idx[:4]], s[idx[4:]] = 64.0, 1.0 / 64.0
+        return s
+
+    def apply(prod, name, cons, cname, c0):
+        s = scales()
+        prod[name + ".weight"] = prod[name + ".weight"] * s[:, None]
+        prod[name + ".bias"] = prod[name + ".bias"] * s
+        cons[cname + ".weight"][:, c0:c0 + 256] *= (1.0 / s)[None, :]
+    for i in range(4):
+        apply(c, "layers.%d" % i, c, "layers.%d" % (i + 1), 0)
+    apply(c, "layers.4", st, "layers.0", 256)
+    for i in range(7):
+        apply(st, "layers.%d" % i, st, "layers.%d" % (i + 1), 0)
+    return c, st
+
+
 def nerf_state_adversarial(seed):
     """White-noise density (no spectral decay, mostly empty space): the ill-conditioned stress scene."""
     return nerf_state(seed, sigma_shift=-40.0, pe_decay=0.0)
