@@ -272,3 +272,22 @@ def test_g14_coherence_term(golden):
     close(rgb2.grad, g["coh_grad_rgb2"], 1e-6)
     close(rgb_fine2.grad, g["coh_grad_rgb_fine2"], 1e-6)
     assert st.cnt == 2 and torch.equal(st.x, rgb2.detach()) and torch.equal(st.y, rgb_fine2.detach())
+
+
+def test_g13_geometry_file():
+    """tests/golden/files/geometry*.npz were written by the REFERENCE's cal_geometry (gen_golden.py g13_files).  The oracle
+    reproduces them: coor_map = o + t * d with the float32 oracle's depth -- to 5e-8 on the CPU that wrote them; another CPU's
+    float32 evaluation may take another branch of the sampler on a few rays (tests/conditioning.py), hence a share."""
+    import os
+    files = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "files")
+    h, w, frames = 6, 8, 3
+    rng = np.random.default_rng(1010)
+    n = frames * h * w
+    ro = np.concatenate([rng.uniform(-1.0, 1.0, (n, 2)), -np.ones((n, 1))], 1).astype(np.float64)
+    rd = np.concatenate([rng.uniform(-0.3, 0.3, (n, 2)), 2.0 * np.ones((n, 1))], 1).astype(np.float64)
+    t32 = fields.render_plain(T(synth.nerf_state(0)), T(synth.nerf_state(1)), tt(ro), tt(rd), 64, 64)["t_fine"].numpy()
+    for name, rays in (("geometry_00001.npz", slice(48, 96)), ("geometry.npz", slice(0, n))):
+        ref = np.load(os.path.join(files, name))["coor_map"]
+        d = np.abs(ref - (ro[rays] + t32[rays, None] * rd[rays]).reshape(ref.shape)).reshape(-1, 3).max(1)
+        print(name, "max %.2e, %d of %d rays within 1e-5" % (d.max(), int((d <= 1e-5).sum()), d.size))
+        assert np.mean(d <= 1e-5) >= 0.9 and d.max() <= 0.1
