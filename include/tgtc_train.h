@@ -35,7 +35,8 @@ int tgtc_trainer_backward(tgtc_trainer* trainer, const float* const* params, con
                           void* stream);
 /* synchronises `stream`; non-zero (with tgtc_last_error) if the last backward overflowed its fp16 operand range */
 int tgtc_trainer_status(tgtc_trainer* trainer, void* stream);
-/* Overflow guard: a backward whose scaled gradients left the fp16 range (growth above ~2^7 across one transposed layer)
+/* Overflow guard: a backward whose scaled gradients left the fp16 range (growth above ~2^7 across one transposed layer), or
+ * that produced any non-finite gradient for whatever reason (a forward that overflowed fp16, non-finite dL/d outputs),
  * ZERO-FILLS grads[0..23] on the device before it returns control to the stream -- an optimiser step on them cannot write
  * inf / NaN into the weights -- and counts the event.  *count = such backwards since trainer_create (synchronises `stream`;
  * read it at the reference's i_print cadence, train_tgtcs.py:257-266, not per iteration). */

@@ -272,36 +272,87 @@ def test_two_forwards_before_one_backward_keep_their_own_stash():
     assert float((parts[0] - parts[1]).abs().max()) > 0.2 * float(parts[0].abs().max())
 
 
+@pytest.mark.parametrize("s_rgb,s_sigma", [(1.0, 1.0), (1e-3, 1e3), (1e3, 1e-3), (1e-6, 1.0), (1.0, 0.0)])
+def test_fused_backward_takes_head_gradients_of_any_ratio(s_rgb, s_sigma):
+    """The sigma row joins the input-gradient chain two layers after the colour head (mlp_train.hip D2): whatever the ratio
+    of the two upstream gradients, the chain's scales must hold both.  (Round 4 found NaN weight gradients for
+    |d sigma| ~ |d rgb| ~ 1: the colour branch had shrunk, the lagged scale had grown, and d sigma left the fp16 range.)
+    Upstream gradients given directly: loss = sum(w_rgb * rgb) + sum(w_sigma * sigma), fused kernels vs float64 autograd."""
+    from tgtc_style_amd import fused_train, models
+    M = 512
+    rng = np.random.default_rng(11)
+    pts = torch.from_numpy(rng.uniform(-1.2, 1.2, (M, 3)))
+    dirs = torch.from_numpy(rng.uniform(-1, 1, (M, 3)))
+    w_rgb = torch.from_numpy(rng.standard_normal((M, 3)) * s_rgb)
+    w_sig = torch.from_numpy(rng.standard_normal((M,)) * s_sigma)
+    sd = synth.nerf_state(1)
+
+    def oracle_grads(dtype):
+        w = {k: v.clone().to(dtype).requires_grad_() for k, v in T(sd).items()}
+        ret = fields.nerf_mlp(w, fields.posenc(pts, 10).to(dtype), fields.posenc(dirs, 4).to(dtype))
+        ((ret["rgb"] * w_rgb.to(dtype)).sum() + (ret["sigma"].reshape(M) * w_sig.to(dtype)).sum()).backward()
+        return {k: v.grad.double() for k, v in w.items()}
+    g64, g32 = oracle_grads(torch.float64), oracle_grads(torch.float32)
+    m = models.StyleNerf(Args, mode="fine")
+    m.load_state_dict(T(sd))
+    m = m.cuda().trainable()
+    before = m.training_overflows()
+    out = m(pts=pts.cuda(), dirs=dirs.cuda())
+    ((out["rgb"] * w_rgb.cuda().float()).sum() + (out["sigma"].reshape(M) * w_sig.cuda().float()).sum()).backward()
+    m._trainer.status()
+    assert m.training_overflows() == before
+    bad = []
+    for k, p in m.state_dict(keep_vars=True).items():
+        scale = float(g64[k].abs().max()) + 1e-30
+        err = float((p.grad.double().cpu() - g64[k]).abs().max()) / scale
+        yard = float((g32[k] - g64[k]).abs().max()) / scale
+        print("%-32s HIP vs f64 %.2e   torch-f32 vs f64 %.2e" % (k, err, yard))
+        bad = bad + [(k, err, yard)] if not err <= max(2e-5, 3 * yard) else bad
+    assert not bad, bad
+
+
 def test_overflow_guard_zero_fills_the_gradients():
-    """growth above ~2^7 in one transposed layer overflows the fp16 operands of the input-gradient chain; the
-    gradients would be inf / NaN and an Adam step would destroy the weights.  The library's guard zero-fills them on the device
-    and counts the event; a normal backward afterwards works and leaves the count alone."""
+    """growth above ~2^7 in one transposed layer overflows the fp16 operands of the input-gradient chain (and a
+    forward that overflows gives NaN gradients); an Adam step on them would destroy the weights.  The library's guard
+    zero-fills non-finite or overflowed gradients on the device and counts the event; a normal backward afterwards works and
+    leaves the count alone."""
     from tgtc_style_amd import fused_train, models
     M = 512
     rng = np.random.default_rng(5)
     pts = torch.from_numpy(rng.uniform(-1.2, 1.2, (M, 3))).cuda()
     dirs = torch.from_numpy(rng.uniform(-1, 1, (M, 3))).cuda()
-    sd = {k: v.copy() for k, v in synth.nerf_state(1).items()}
-    sd["net.base_layers.6.weight"] *= 3.0e4          # dL/dh grows by ~2^15 across this transposed layer
     m = models.StyleNerf(Args, mode="fine")
-    m.load_state_dict(T(sd))
     m = m.cuda().trainable()
-    before = m.training_overflows()
-    out = m(pts=pts, dirs=dirs)
-    (out["rgb"].sum() + out["sigma"].sum()).backward()
-    with pytest.raises(RuntimeError, match="fp16 range"):
-        m._trainer.status()
-    assert m.training_overflows() == before + 1
-    for p in fused_train.mlp_parameters(m.net):
-        assert bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) == 0.0
+    fired = []
+    # (a) the backward's own range: layer 7 shrinks the gradient by 2^-k, layer 6 grows it back by 2^k -- the forward stays in
+    # range, the chain's scale (one layer behind) does not; (b) a forward that leaves the fp16 range outright
+    cases = [("chain 2^%d" % k, {"net.base_layers.6.weight": 2.0 ** k, "net.base_layers.7.weight": 2.0 ** -k}) for k in (10, 14, 18)]
+    cases.append(("forward", {"net.base_layers.3.weight": 1e6}))
+    for name, scale in cases:
+        sd = {k: v.copy() * np.float32(scale.get(k, 1.0)) for k, v in synth.nerf_state(1).items()}
+        m.load_state_dict({k: v.cuda() for k, v in T(sd).items()})
+        m.zero_grad()
+        before = m.training_overflows()
+        out = m(pts=pts, dirs=dirs)
+        (out["rgb"].sum() + out["sigma"].sum()).backward()
+        hit = m.training_overflows() - before
+        grads = [p.grad for p in fused_train.mlp_parameters(m.net)]
+        assert all(bool(torch.isfinite(g).all()) for g in grads), name          # never a non-finite gradient, fired or not
+        if hit:
+            fired.append(name)
+            assert hit == 1 and all(float(g.abs().max()) == 0.0 for g in grads), name
+            with pytest.raises(RuntimeError, match="fp16 range"):
+                m._trainer.status()
+        print(name, "-> guard fired" if hit else "-> in range")
+    assert "forward" in fired and any(n.startswith("chain") for n in fired), fired
     # a well-scaled network on the same trainer: finite, non-zero gradients, counter unchanged
+    before = m.training_overflows()
     m.load_state_dict({k: v.cuda() for k, v in T(synth.nerf_state(1)).items()})
     m.zero_grad()
     out = m(pts=pts, dirs=dirs)
     (out["rgb"].sum() + out["sigma"].sum()).backward()
     m._trainer.status()
-    assert m.training_overflows() == before + 1
-    assert all(bool(torch.isfinite(p.grad).all()) for p in fused_train.mlp_parameters(m.net))
+    assert m.training_overflows() == before
     assert float(fused_train.mlp_parameters(m.net)[0].grad.abs().max()) > 0
 
 

@@ -7,10 +7,12 @@
 #include "mlp_mx.h"
 #include "mx_asm.h"
 
-// 1: in the persistent (fused ray kernel) FULL pass the 256 -> 256 layers 1-4, 6-7 and 9 run as the generated instruction
-// streams of tools/gen_mx_asm.py (mx_asm_nerf.inc; bit-identical to dense_mx, profiles/r4_kernel_variants.md)
+// The generated instruction streams of tools/gen_mx_asm.py (mx_asm_nerf.inc; profiles/r4_kernel_variants.md) in the fused ray
+// kernel's FULL fp16mx pass.  2 (shipped): the whole pass -- all twelve layers -- is ONE stream (render_fused.h); 1: only the
+// 256 -> 256 layers 1-4 and 6-7, as blocks between HIP layers (measured 1.5 % slower than 0: every HIP <-> asm transition
+// drains the LDS queue); 0: the HIP loop (dense_mx) everywhere.  The per-sample kernel always runs the HIP loop.
 #ifndef TGTC_MX_ASM
-#define TGTC_MX_ASM 0
+#define TGTC_MX_ASM 2
 #endif
 
 namespace tgtc {

@@ -355,7 +355,7 @@ struct BwdArgs {
     const unsigned long long* gates;
     long long n_tiles;
     float* dz;               // segments of [M_pad][width] (train_layouts.h)
-    unsigned* maxima;        // [11] bit patterns of max |dz| per dZ segment (dz0..7, remap, f, heads); non-negative floats order as ints
+    unsigned* maxima;        // [12] bit patterns of max |dz| per dZ segment (dz0..7, remap, f, colour head, sigma head); non-negative floats order as ints
     unsigned* status;        // [1]  set to 1 if a scaled gradient left the fp16 range
 };
 
@@ -367,9 +367,12 @@ __device__ __forceinline__ float wave_max(float m) {
 // power-of-two scale exponent that brings a tile maximum to ~2^8 (fp16 hi/lo operands: 2^7 of headroom, 2^22 below)
 __device__ __forceinline__ int scale_exp(float tile_max, int keep) {
     const unsigned b = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, tile_max));
-    return b == 0 ? keep : 8 - ((int)(b >> 23) - 127);
+    // (bounded: a tile whose largest gradient is below 2^-92 -- samples behind an opaque surface reach fp32 denormals -- is
+    // scaled by 2^100 and no further.  Unbounded, a maximum in [2^-120, 2^-119) asked for 2^128 = inf, and the tile's
+    // zero entries times inf put NaNs into every gradient: round 4 found the guard firing in ordinary Origin_train steps)
+    return b == 0 ? keep : max(-100, min(100, 8 - ((int)(b >> 23) - 127)));
 }
-__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
+__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(max(-126, min(127, e)) + 127) << 23); }
 
 // signed hi/lo split of a pair (no ReLU): hi = fp16(v), lo = fp16(v - hi) (split_pair without the integer max)
 __device__ __forceinline__ void split_pair_signed(float v0, float v1, unsigned& hpk, unsigned& lpk) {
@@ -452,16 +455,27 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
     *reinterpret_cast<float4v*>(seg_row(Z_HEADS, 16) + 4 * g) = g == 0 ? float4v{hd[0], hd[1], hd[2], hd[3]} : float4v{0.f, 0.f, 0.f, 0.f};
     // segment maxima of this wave's tile: kept (wave-uniform) until the chain is through and published then -- an atomic is
     // a vector-memory operation, and one per layer in front of the ring's counted waits stalled every layer's first chunks
-    unsigned seg_max[11];
-    float m = wave_max(fmaxf(fmaxf(fabsf(hd[0]), fabsf(hd[1])), fmaxf(fabsf(hd[2]), fabsf(hd[3]))));
+    unsigned seg_max[12];
+    // The two heads carry their own scales (and their own segment maxima, 10: colour, 11: sigma): d sigma and dz_rgb may be
+    // orders of magnitude apart (compositing gives |d sigma| ~ 1e-3 |d rgb| early in training and the reverse is as legal),
+    // and the smaller one at the larger one's scale loses its low bits to fp16.  The colour head's values enter at D0, the
+    // sigma row at D2 -- two layers after the colour branch has shrunk its values and the lagged scale has grown: no scale up to
+    // and including D2's outputs may exceed the one d sigma fits in, or d sigma (and the products it feeds) leave the fp16
+    // range: hi = inf, lo = x - inf, and the layer sums to NaN without any inf left for the maxima to show (round 4).
+    const float m_sig = wave_max(fabsf(hd[0]));
+    float m = wave_max(fmaxf(fabsf(hd[1]), fmaxf(fabsf(hd[2]), fabsf(hd[3]))));
     seg_max[10] = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, m));
-    int e_in = scale_exp(m, 0);
-    auto heads_frag = [&](int e, half8& h, half8& l) {   // natural order k = 8g + j: the four values sit in lane group 0
+    seg_max[11] = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, m_sig));
+    const int e_sig = scale_exp(m_sig, 100);   // (no sigma gradient in this tile: no constraint)
+    int e_in = scale_exp(m, e_sig);            // (no colour gradient: the branch carries zeros, at the scale sigma will need)
+    // natural order k = 8g + j: the four values sit in lane group 0; SIGMA: the sigma entry alone (D2), else the colour entries (D0)
+    auto heads_frag = [&](auto sigma_, int e, half8& h, half8& l) {
+        constexpr bool SIGMA = decltype(sigma_)::value;
         const float sc = pow2f(e);
         unsigned h01 = 0, l01 = 0, h23 = 0, l23 = 0;
         if (g == 0) {
-            split_pair_signed(hd[0] * sc, hd[1] * sc, h01, l01);
-            split_pair_signed(hd[2] * sc, hd[3] * sc, h23, l23);
+            split_pair_signed(SIGMA ? hd[0] * sc : 0.f, SIGMA ? 0.f : hd[1] * sc, h01, l01);
+            split_pair_signed(SIGMA ? 0.f : hd[2] * sc, SIGMA ? 0.f : hd[3] * sc, h23, l23);
         }
         h = __builtin_bit_cast(half8, u4{h01, h23, 0u, 0u});
         l = __builtin_bit_cast(half8, u4{l01, l23, 0u, 0u});
@@ -474,21 +488,21 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
     float pend[2];
     // after a layer: the tile maximum of its gated outputs fixes the scale of the layer AFTER the next (the next layer's
     // operands were already produced at the scale derived one layer earlier); segment maxima feed the weight-gradient kernel
-    auto close = [&](auto seg_, float& mm, int keep) {
+    auto close = [&](auto seg_, float& mm, int cur, int keep) {   // cur: the scale in force, keep: the answer for an all-zero tile
         const float t = wave_max(mm);
         seg_max[decltype(seg_)::value] = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, t));
 #ifdef TGTC_DGRAD_ATOMIC_PER_LAYER   // A/B build: the round's first form, one atomic per layer in front of the ring waits
         if (lane == 0) atomicMax(a.maxima + decltype(seg_)::value, __builtin_bit_cast(unsigned, t));
 #endif
         mm = 0.f;
-        return scale_exp(t, keep);
+        return max(cur - 120, min(cur + 120, scale_exp(t, keep)));   // (s_op = 2^(difference of consecutive scales) stays a normal float)
     };
 
     // D0: rgb_layers.1^T.  inputs heads (scale e_in), outputs dz_f at the same scale (|W| < 1: the values shrink)
     int e_out = e_in, e_next;
     {
         half8 Bh[1][1], Bl[1][1];
-        heads_frag(e_in, Bh[0][0], Bl[0][0]);
+        heads_frag(std::false_type{}, e_in, Bh[0][0], Bl[0][0]);
         half8 Zh[4][1], Zl[4][1];
         m = 0.f;
         {
@@ -499,7 +513,7 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
                 dgrad_epi<rt, hf, true>(acc, gw[9], s_true, s_op, m, pend, zrow, g, Zh[rt / 2][0], Zl[rt / 2][0]);
             });
         }
-        e_next = close(ic<9>{}, m, e_out);
+        e_next = min(close(ic<9>{}, m, e_out, e_sig), e_sig);
         // D1: rgb_layers.0^T (activation columns): dz_f -> dz_remap
         e_in = e_out, e_out = e_next;
         {
@@ -510,7 +524,7 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
                 dgrad_epi<rt, hf, true>(acc, gw[8], s_true, s_op, m, pend, zrow, g, Yh[rt / 2][0], Yl[rt / 2][0]);
             });
         }
-        e_next = close(ic<8>{}, m, e_out);
+        e_next = min(close(ic<8>{}, m, e_out, e_sig), e_sig);
     }
     // D2: [base_remap^T | sigma^T]: [dz_remap | heads] -> dz_7
     e_in = e_out, e_out = e_next;
@@ -518,7 +532,7 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
         half8 Bh[9][1], Bl[9][1];
 #pragma unroll
         for (int k = 0; k < 8; ++k) Bh[k][0] = Yh[k][0], Bl[k][0] = Yl[k][0];
-        heads_frag(e_in, Bh[8][0], Bl[8][0]);
+        heads_frag(std::true_type{}, e_in, Bh[8][0], Bl[8][0]);
         const float s_true = pow2f(-e_in), s_op = pow2f(e_out - e_in);
         float* const zrow = seg_row(z_layer(7), 256);
         dense_layer<C, dgrad_frag0(2), 9, 16, 0>(ws, bias_lane, Bh, Bl, [&](auto rt_, auto, auto h_, const float4v& acc) {
@@ -526,7 +540,7 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
             dgrad_epi<rt, hf, true>(acc, gw[7], s_true, s_op, m, pend, zrow, g, Xh[rt / 2][0], Xl[rt / 2][0]);
         });
     }
-    e_next = close(ic<7>{}, m, e_out);
+    e_next = close(ic<7>{}, m, e_out, e_out);
     // D3..D9: base_layers[7..1]^T: dz_l -> dz_{l-1}
     auto hidden = [&](auto d_, auto last_, const half8 (&Ih)[8][1], const half8 (&Il)[8][1], half8 (&Oh)[8][1], half8 (&Ol)[8][1]) {
         constexpr int d = decltype(d_)::value, l_out = 9 - d;          // D3 -> dz_6 ... D9 -> dz_0
@@ -538,7 +552,7 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
             constexpr int rt = decltype(rt_)::value, hf = decltype(h_)::value;
             dgrad_epi<rt, hf, !last>(acc, gw[l_out], s_true, s_op, m, pend, zrow, g, Oh[rt / 2][0], Ol[rt / 2][0]);
         });
-        e_next = close(ic<l_out>{}, m, e_out);
+        e_next = close(ic<l_out>{}, m, e_out, e_out);
     };
     hidden(ic<3>{}, std::false_type{}, Xh, Xl, Yh, Yl);
     hidden(ic<4>{}, std::false_type{}, Yh, Yl, Xh, Xl);
@@ -551,14 +565,14 @@ __global__ void __launch_bounds__(CfgT::NWAVES * 64, 2) train_dgrad_kernel(BwdAr
     // report instead of returning garbage
     bool bad = false;
 #pragma unroll
-    for (int i = 0; i < 11; ++i) bad |= (seg_max[i] & 0x7f800000u) == 0x7f800000u;
+    for (int i = 0; i < 12; ++i) bad |= (seg_max[i] & 0x7f800000u) == 0x7f800000u;
     // lane i publishes segment i, and only if it raises the table (one coherent load + one masked atomic per wave; after the
     // first few tiles almost no lane has anything to add.  One unconditional atomic per wave and segment -- 90 000 on eleven
     // addresses -- cost 0.2 ms of the kernel wherever they were issued)
     unsigned mine = 0;
 #pragma unroll
-    for (int i = 0; i < 11; ++i) mine = lane == i ? seg_max[i] : mine;
-    if (lane < 11 && mine > __hip_atomic_load(a.maxima + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.maxima + lane, mine);
+    for (int i = 0; i < 12; ++i) mine = lane == i ? seg_max[i] : mine;
+    if (lane < 12 && mine > __hip_atomic_load(a.maxima + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.maxima + lane, mine);
     if (bad && lane == 0) atomicMax(a.status, 1u);
 }
 
@@ -640,8 +654,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgradJob& J
     half_t* const Blo = Bhi + 32 * SB;
 
     // scale of the dZ operand: a power of two that brings the segment maximum to ~2^10
-    const unsigned mb = a.maxima[seg_of_zcol(J.z_col)];
-    const int e_sc = mb == 0 ? 0 : 10 - ((int)(mb >> 23) - 127);
+    const unsigned mb = a.maxima[J.z_col == Z_HEADS && J.layer == 8 ? 11 : seg_of_zcol(J.z_col)];   // (the sigma row has its own maximum)
+    const int e_sc = mb == 0 ? 0 : max(-100, min(100, 10 - ((int)(mb >> 23) - 127)));   // (bounded like scale_exp)
     const float sc = pow2f(e_sc);
 
     float4v acc[KT];
@@ -856,7 +870,7 @@ extern "C" int tgtc_trainer_create(tgtc_trainer** out) {
     tr->bwd_map_off = take(bwd.size() * sizeof(PackSrc));
     tr->fwd_bias_map_off = take(bias.size() * sizeof(PackSrc));
     tr->unperm_off = take(unperm.size() * sizeof(short));
-    tr->maxima_off = take(64);                                                         // 11 segment maxima + status word
+    tr->maxima_off = take(64);                                                         // 12 segment maxima + status word
     tr->fwd_stream_off = take(kNerfBiasBytes + tr->fwd_stream_bytes + kRingBytes);     // [bias table][stream][slack for the look-ahead]
     tr->bwd_stream_off = take(kNerfBiasBytes + tr->bwd_stream_bytes + kRingBytes);     // [zeros][stream][slack]
     hipError_t e = hipMalloc((void**)&tr->dev, off);
@@ -887,6 +901,15 @@ struct GuardArgs {
     float* g[24];
     unsigned n[24];
 };
+// (first pass of the guard) any non-finite gradient raises the flag too, whatever produced it: a forward that overflowed fp16,
+// non-finite dL/d outputs -- fmaxf drops NaNs, so the chain's own maxima cannot see those.  2.4 MB of reads.
+__global__ void __launch_bounds__(256) nonfinite_scan_kernel(unsigned* status, GuardArgs a) {
+    bool bad = false;
+    for (int i = 0; i < 24; ++i)
+        for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < a.n[i]; k += gridDim.x * blockDim.x)
+            bad |= (__builtin_bit_cast(unsigned, a.g[i][k]) & 0x7f800000u) == 0x7f800000u;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicMax(status, 1u);
+}
 __global__ void __launch_bounds__(256) overflow_guard_kernel(const unsigned* status, unsigned* count, GuardArgs a) {
     if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     for (int i = 0; i < 24; ++i)
@@ -953,7 +976,7 @@ extern "C" int tgtc_trainer_backward(tgtc_trainer* tr, const float* const* param
                                                                     reinterpret_cast<half_t*>(bs + kNerfBiasBytes), nullptr, 0, nullptr);
     TGTC_LAUNCH_CHECK();
     unsigned* maxima = reinterpret_cast<unsigned*>(tr->dev + tr->maxima_off);
-    TGTC_HIP_CHECK(hipMemsetAsync(maxima, 0, 52, st));    // 11 segment maxima, status word at +48; the overflow counter at +52 survives
+    TGTC_HIP_CHECK(hipMemsetAsync(maxima, 0, 52, st));    // 12 segment maxima, status word at +48; the overflow counter at +52 survives
     static const int shape[12][2] = {{256, 63}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 319}, {256, 256}, {256, 256},
                                      {1, 256},  {256, 256}, {128, 283}, {3, 128}};
     {   // the weight-gradient kernel accumulates: zero-fill first (ONE fill when the caller laid the 24 tensors out back to back)
@@ -996,6 +1019,10 @@ extern "C" int tgtc_trainer_backward(tgtc_trainer* tr, const float* const* param
         ga.g[2 * l] = grads[2 * l], ga.n[2 * l] = (unsigned)(shape[l][0] * shape[l][1]);
         ga.g[2 * l + 1] = grads[2 * l + 1], ga.n[2 * l + 1] = (unsigned)shape[l][0];
     }
+#ifndef TGTC_ABL_NOSCAN   // (development builds can leave the scan out to see which of the two raised the flag)
+    nonfinite_scan_kernel<<<64, 256, 0, st>>>(maxima + 12, ga);
+    TGTC_LAUNCH_CHECK();
+#endif
     overflow_guard_kernel<<<64, 256, 0, st>>>(maxima + 12, maxima + 13, ga);
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;
@@ -1013,6 +1040,6 @@ extern "C" int tgtc_trainer_status(tgtc_trainer* tr, void* stream) {
     unsigned s = 0;
     TGTC_HIP_CHECK(hipMemcpyAsync(&s, tr->dev + tr->maxima_off + 48, sizeof(s), hipMemcpyDeviceToHost, (hipStream_t)stream));
     TGTC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    if (s) return fail(TGTC_ERR_UNSUPPORTED, "trainer: a scaled gradient left the fp16 range in the last backward (gradients are not finite)");
+    if (s) return fail(TGTC_ERR_UNSUPPORTED, "trainer: a scaled gradient left the fp16 range in the last backward, or a gradient came out non-finite (the gradients were zero-filled)");
     return TGTC_OK;
 }

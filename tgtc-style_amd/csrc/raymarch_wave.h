@@ -8,6 +8,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "mlp_core.h"
+
 #pragma clang fp contract(off)
 
 namespace tgtc {
@@ -52,27 +54,39 @@ struct RayAccum {
 // wave calls it (row-wide shuffles); lanes 16..63 compute on copies of zero rows and their results are unused.
 // The transmittance is the SEQUENTIAL product of the reference (sample after sample, in float64), so the weights --
 // and with them the inverse-CDF samples, which are discontinuous in the weights -- do not depend on how a kernel tiles a ray.
+// Lane K of this lane's row of 16 / the row rotated by R lanes, as DPP moves (row_newbcast, row_ror): no LDS, no address
+// registers.  (`__shfl(v, k, 16)` builds sixteen per-lane ds_bpermute addresses from the lane id, which hipcc hoists out of a
+// caller's tile loop and keeps -- or spills -- across the passes.)  Rotations by 8, 4, 2, 1 add up a row exactly like the
+// xor butterfly: the partial sums of step s have period 16 >> s, so lane i + r and lane i ^ r hold the same value.
+template <int K>
+__device__ __forceinline__ float row_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xf, 0xf, false));
+}
+template <int R>
+__device__ __forceinline__ float row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + R, 0xf, 0xf, false));
+}
+
 template <bool COLOUR>
 __device__ __forceinline__ float composite_tile(float sigma, float cr, float cg, float cb, float t, float delta, RayAccum& acc) {
-    int n = threadIdx.x & 15;
-    asm volatile("" : "+v"(n));   // not hoistable out of a caller's loop (render_fused.hip)
+    const int n = fresh_lane_id() & 15;   // read in place: not hoistable out of a caller's loop (render_fused.hip)
     const float dens = fmaxf(fmaxf(sigma, 0.0f), 0.0f);          // relu(relu(.)) utils.py:365,376
     const float alpha = 1.0f - expf(-dens * delta);
     const float keep = 1.0f - alpha + 1e-10f;
     double run = acc.trans, mine = acc.trans;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    static_for<16>([&](auto k_) {
+        constexpr int k = decltype(k_)::value;
         if (n == k) mine = run;
-        run = run * (double)__shfl(keep, k, 16);
-    }
+        run = run * (double)row_bcast<k>(keep);
+    });
     acc.trans = run;
     const float w = alpha * (float)mine;
     float s0 = COLOUR ? w * cr : 0.0f, s1 = COLOUR ? w * cg : 0.0f, s2 = COLOUR ? w * cb : 0.0f, s3 = w * t;
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-        if constexpr (COLOUR) s0 = s0 + __shfl_xor(s0, off, 16), s1 = s1 + __shfl_xor(s1, off, 16), s2 = s2 + __shfl_xor(s2, off, 16);
-        s3 = s3 + __shfl_xor(s3, off, 16);
-    }
+    static_for<4>([&](auto s_) {
+        constexpr int off = 8 >> decltype(s_)::value;
+        if constexpr (COLOUR) s0 = s0 + row_ror<off>(s0), s1 = s1 + row_ror<off>(s1), s2 = s2 + row_ror<off>(s2);
+        s3 = s3 + row_ror<off>(s3);
+    });
     acc.r = acc.r + s0, acc.g = acc.g + s1, acc.b = acc.b + s2, acc.t = acc.t + s3;
     return w;
 }

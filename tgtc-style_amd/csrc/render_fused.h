@@ -99,9 +99,26 @@ __device__ __forceinline__ void fused_pass(char* smem, int wave, int lane, const
         st.template enter<0, NQ>();
         st.ring.next = next_src;         // ... and the one its look-ahead runs into
         const half8 Ph[2] = {pe_h[0][0], pe_h[1][0]}, Pl[2] = {pe_l[0][0], pe_l[1][0]};
+#if TGTC_MX_ASM == 2
+        if constexpr (FULL && C::SLOTS == 8 && kChunkBytes == 16384) {
+            // the whole pass as ONE generated instruction stream (tools/gen_mx_asm.py, mx_asm_nerf.inc): the encodings go in
+            // pinned, sigma and the colour head's accumulator come out; nothing else of this function lives across it
+            half8 keep[6] = {Ph[0], Ph[1], Pl[0], Pl[1], half8{}, half8{}};
+            encode_dir<true, true>(d, g, keep[4], keep[5], nullptr);
+            st.relane(smem, wave);
+            const int fl = fresh_lane_id();
+            const lds_cptr bl = opaque((lds_cptr)smem + C::RING_BYTES + 16 * (fl >> 4));
+            const lds_cptr rl = opaque((lds_cptr)smem + C::RING_BYTES + kNerfMxScaleOff + 2 * (fl & 15));
+            float sigma, rgb[3];
+            mx_asm_nerf_full_pass(st, bl, rl, keep, sigma, rgb);
+            st.relane(smem, wave);
+            sig[0] = sigma;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) col[0][r] = 1.0f / (1.0f + expf(-rgb[r]));   // models.py:111
+        } else
+#endif
         nerf_chain_mx<C, FULL>(
-            st, bias_lane, rs_lane, Ph, Pl,
-            [&](half8& dh, half8& dl) { encode_dir<true, true>(d, g, dh, dl, nullptr); },
+            st, bias_lane, rs_lane, Ph, Pl, [&](half8& dh, half8& dl) { encode_dir<true, true>(d, g, dh, dl, nullptr); },
             [&](float s) { sig[0] = s; }, [](auto, auto, const float4v&) {},
             [&](auto h_, const float4v& acc) { colour(ic<0>{}, h_, acc); }, smem, wave);
         st.template finish<NQ>();

@@ -344,6 +344,294 @@ class BlockGen:
         return e.lines
 
 
+# ================================================================================================ the whole pass
+# All twelve layers of the fp16mx NeRF pass (mlp_nerf_mx_chain.h nerf_chain_mx, FULL) as ONE stream: encoding groups (fp16
+# hi / lo k-steps, three products each), the skip layer, the sigma head, base_remap, the colour head.  Nothing of the
+# compiler's is live across it but the per-lane addresses; the encodings come in pinned (v16..v39), sigma and the colour
+# head's accumulator go out in v12..v15.
+class Layer:
+    def __init__(self, name, rt, nkb, npe, src, sink, pe):
+        self.name, self.rt, self.nkb, self.npe, self.src, self.sink, self.pe = name, rt, nkb, npe, src, sink, pe
+
+
+KEEP = {"pe": (16, 24), "dir": (32, 36)}     # (hi base, lo base): Ph[k] = v[16+4k..], Pl[k] = v[24+4k..]; Dh = v[32..35], Dl = v[36..39]
+OUT_SIG, OUT_RGB = 12, 13                     # v12: sigma; v13..v15: the colour head's accumulator rows 0..2
+
+
+def nerf_full_layers():
+    A, B = R.A, R.B
+    return [Layer("L0", 16, 0, 2, None, A, "pe"), Layer("L1", 16, 2, 0, A, B, None), Layer("L2", 16, 2, 0, B, A, None),
+            Layer("L3", 16, 2, 0, A, B, None), Layer("L4", 16, 2, 0, B, A, None), Layer("L5", 16, 2, 2, A, B, "pe"),
+            Layer("L6", 16, 2, 0, B, A, None), Layer("L7", 16, 2, 0, A, B, None), Layer("SIG", 1, 2, 0, B, "sigma", None),
+            Layer("REMAP", 16, 2, 0, B, A, None), Layer("C0", 8, 2, 1, A, B, "dir"), Layer("C1", 1, 1, 0, B, "rgb", None)]
+
+
+class PassGen(BlockGen):
+    def __init__(self, table, layers, nq_pass, padc, cfg):
+        BlockGen.__init__(self, table, 0, 0, 0, nq_pass, padc, cfg)
+        self.layers = layers
+        self.qend = nq_pass
+        self.exit_entered = max(table.chunk_hi(nq_pass - 1) - 1, 0)
+        self.entered = 0                                     # enter<0, NQ>() has run the boundary of virtual chunk 0
+
+    def readable(self, q):
+        return q < self.nq
+
+    def acquire_for(self, q):
+        g = min(q, self.nq - 1)
+        want = self.t.chunk_hi(g) - 1
+        while self.entered < want:
+            self.boundary(self.entered + 1)
+
+    # units of a group: (unit id, register offset in the buffer, registers, byte offset in the group, wide)
+    def units(self, q):
+        n = self.t.npe[q]
+        if n:
+            return [(j, 4 * j, 4, 1024 * j, True) for j in range(2 * n)]
+        return [(0, 0, 4, 0, True), (1, 4, 4, 1024, True), (2, 8, 4, 2048, True), (3, 12, 4, 3072, True),
+                (4, 16, 4, 4096, True), (6, 20, 2, 6144, False), (5, 22, 4, 5120, True), (7, 26, 2, 6656, False)]
+
+    def read_unit_at(self, q, unit):
+        u, roff, nreg, boff, wide = unit
+        t, e = self.t, self.e
+        assert t.chunk_hi(q) - 1 <= self.entered, "group %d read before its chunks were entered" % q
+        o = t.off[q] % RING
+        w = self.wbase(q)
+        off = o + boff
+        if wide:
+            base = "%[lane_lo]" if off < 65536 else "%[lane_hi]"
+            op = e.lds("ds_read_b128 %s, %s offset:%d" % (vr(w + roff, 4), base, off % 65536))
+        else:
+            base = "%[b8_lo]" if off < 65536 else "%[b8_hi]"
+            op = e.lds("ds_read_b64 %s, %s offset:%d" % (vr(w + roff, 2), base, off % 65536))
+        self.unit_op[(q, u)] = op
+        self.unit_chunk[op] = (t.off[q] + boff) // CHUNK
+
+    def mfmas(self, q, layer, acc, rs):
+        """the MFMA instructions of group q with, for each, the buffer registers it is the LAST reader of"""
+        w = self.wbase(q)
+        n = self.t.npe[q]
+        out = []
+        f16 = "v_mfma_f32_16x16x32_f16 %s, %s, %s, %s"
+        if n:
+            hi0, lo0 = KEEP[layer.pe]
+            for k in range(n):
+                ph, pl = vr(hi0 + 4 * k, 4), vr(lo0 + 4 * k, 4)
+                uh, ul = w + 8 * k, w + 8 * k + 4
+                out.append((f16 % (vr(acc, 4), vr(uh, 4), ph, vr(acc, 4)), []))
+                out.append((f16 % (vr(acc, 4), vr(ul, 4), ph, vr(acc, 4)), list(range(8 * k + 4, 8 * k + 8))))
+                out.append((f16 % (vr(acc, 4), vr(uh, 4), pl, vr(acc, 4)), list(range(8 * k, 8 * k + 4))))
+            return out
+        # which 128-deep block of the source: the group's position among the row tile's K groups
+        kb = self.group_kb[q]
+        x = layer.src
+        sc = "op_sel:[%d,%d,0] op_sel_hi:[0,0,0] cbsz:2 blgp:2"
+        fp6 = "v_mfma_scale_f32_16x16x128_f8f6f4 %s, %s, %s, %s, %s, %s " + sc
+        for j, (kind, idx) in enumerate((("M", 0), ("C", 1), ("M", 1), ("M", 2), ("C", 2), ("M", 3))):
+            if kind == "M":
+                out.append((f16 % (vr(acc, 4), vr(w + 4 * idx, 4), vr(x + ACT_H + 4 * (4 * kb + idx), 4), vr(acc, 4)),
+                            list(range(4 * idx, 4 * idx + 4))))
+            elif idx == 1:
+                out.append((fp6 % (vr(acc, 4), vr(w + 16, 6), vr(x + ACT_H6 + 6 * kb, 6), vr(acc, 4), vr(rs), vr(x + ACT_SC + kb), 1, 0),
+                            list(range(16, 22))))
+            else:
+                out.append((fp6 % (vr(acc, 4), vr(w + 22, 6), vr(x + ACT_L6 + 6 * kb, 6), vr(acc, 4), vr(rs), vr(x + ACT_SC + kb), 0, 1),
+                            list(range(22, 28))))
+        return out
+
+    def generate(self):
+        e, cfg, t = self.e, self.cfg, self.t
+        dist = 2
+        accs = [R.ACC, R.ACC + 4, R.ACC + 8]
+        # the groups in stream order, with their layer / row tile / role
+        groups, self.group_kb = [], {}
+        rows = []                                  # global row tiles: (layer index, rt, [groups])
+        q = 0
+        bias0 = 0
+        for li, L in enumerate(self.layers):
+            L.bias0 = bias0
+            bias0 += 16 * L.rt
+            for rt in range(L.rt):
+                gs = []
+                for kb in range(L.nkb):
+                    assert t.npe[q] == 0
+                    self.group_kb[q] = kb
+                    gs.append(q)
+                    q += 1
+                if L.npe:
+                    assert t.npe[q] == L.npe, (L.name, q, t.npe[q])
+                    gs.append(q)
+                    q += 1
+                rows.append((li, rt, gs))
+        assert q == self.nq, (q, self.nq)
+        total_rt = len(rows)
+        bias_op = {}
+
+        def load_bias(grt):
+            if grt >= total_rt:
+                return
+            li, rt, _ = rows[grt]
+            L = self.layers[li]
+            boff = L.bias0 + 16 * rt
+            e.lds("ds_read_b128 %s, %%[bias_lane] offset:%d" % (vr(accs[grt % 3], 4), boff * 4))
+            if L.nkb:
+                bias_op[grt] = e.lds("ds_read_u16 %s, %%[rs_lane] offset:%d" % (vr(R.RS + grt % 3), boff * 2))
+            else:
+                bias_op[grt] = e.lds_issued - 1
+
+        fillers = []
+        tail_of = [None]                           # (set, block) the pending fillers still have to complete
+
+        def run_filler(grt):
+            f = fillers.pop(0)
+            if isinstance(f, tuple) and f[0] == "ACC_FREE":
+                load_bias(f[1] + 3)                  # the set row f[1] accumulated in is used next by row f[1] + 3
+            else:
+                f()
+
+        def flush(grt, gap=99):
+            # the fillers start by reading the previous row tile's accumulator: fewer than three MFMAs behind its last one
+            # (a one-block layer read by the very next row tile: C0 -> C1) the result is not there yet -- drain explicitly
+            if fillers and gap < 3:
+                e.emit("s_nop 7")
+                e.emit("s_nop 7")
+            while fillers:
+                run_filler(grt)
+            tail_of[0] = None
+
+        def epilogue(grt):
+            """fillers of row tile grt's epilogue"""
+            li, rt, _ = rows[grt]
+            L = self.layers[li]
+            acc = accs[grt % 3]
+            if L.sink == "sigma":
+                return [lambda: e.emit("v_mov_b32_e32 %s, %s" % (vr(OUT_SIG), vr(acc))), ("ACC_FREE", grt)]
+            if L.sink == "rgb":
+                return [lambda i=i: e.emit("v_mov_b32_e32 %s, %s" % (vr(OUT_RGB + i), vr(acc + i))) for i in range(3)] + [("ACC_FREE", grt)]
+            return [("ACC_FREE", grt) if f == "ACC_FREE" else f for f in self.epi_ops(rt, L.sink, acc)]
+
+        for r in range(3):
+            load_bias(r)
+        self.acquire_for(1)
+        for unit in self.units(1):
+            self.read_unit_at(1, unit)
+
+        free = {0: set(), 1: set()}                # buffer parity -> buffer registers no MFMA of the running group needs any more
+        pending = {}                               # group -> units still to read
+        for grt, (li, rt, gs) in enumerate(rows):
+            L = self.layers[li]
+            acc, rs = accs[grt % 3], R.RS + grt % 3
+            if grt > 0:
+                pli, prt, _ = rows[grt - 1]
+                PL = self.layers[pli]
+                fillers.extend(epilogue(grt - 1))
+                if isinstance(PL.sink, int):
+                    tail_of[0] = (PL.sink, prt // 8)
+            n_row = sum(3 * t.npe[g] if t.npe[g] else 6 for g in gs)
+            gap = 0
+            for g in gs:
+                # a K group that reads the block the pending fillers are still producing: they run first
+                if t.npe[g] == 0 and tail_of[0] == (L.src, self.group_kb[g]):
+                    flush(grt, gap)
+                if t.npe[g] == 0 and fillers and tail_of[0] is not None and tail_of[0][0] == L.src and L.nkb == 1:
+                    flush(grt, gap)
+                self.acquire_for(g + dist)
+                ops_needed = [self.unit_op[(g, u[0])] for u in self.units(g) if (g, u[0]) in self.unit_op]
+                if g == gs[0]:
+                    ops_needed.append(bias_op[grt])
+                if ops_needed:
+                    e.need(max(ops_needed))
+                par = g & 1
+                used = set()
+                for u in self.units(g):
+                    used |= set(range(u[1], u[1] + u[2]))
+                free[par] = set(range(28)) - used
+                nxt = g + dist
+                pending = list(self.units(nxt)) if self.readable(nxt) else []
+
+                def issue_ready():
+                    for unit in list(pending):
+                        if set(range(unit[1], unit[1] + unit[2])) <= free[par]:
+                            self.read_unit_at(nxt, unit)
+                            pending.remove(unit)
+                issue_ready()
+                for text, released in self.mfmas(g, L, acc, rs):
+                    e.emit(text)
+                    free[par] |= set(released)
+                    issue_ready()
+                    if gap >= 2 and fillers:
+                        # deadline: the first later group of this row tile that will flush (same rule as above), else the row's end
+                        remaining = max(n_row - 1 - gap, 0) + 1
+                        if tail_of[0] is not None and tail_of[0][0] == L.src:
+                            first_dep = 0
+                            seen = 0
+                            for gg in gs:
+                                cnt = 3 * t.npe[gg] if t.npe[gg] else 6
+                                if t.npe[gg] == 0 and self.group_kb[gg] == tail_of[0][1]:
+                                    first_dep = seen
+                                    break
+                                seen += cnt
+                            remaining = max(first_dep - 1 - gap, 0) + 1
+                        n = (len(fillers) + remaining - 1) // remaining     # a row's epilogue always finishes within the next row
+                        for _ in range(n):
+                            if fillers:
+                                run_filler(grt)
+                    gap += 1
+                assert not pending, "units of group %d could not be placed" % nxt
+            if not fillers:
+                tail_of[0] = None
+        # the colour head's accumulator: drained, then exported
+        e.emit("s_nop 7")
+        e.emit("s_nop 7")
+        fillers.extend(epilogue(total_rt - 1))
+        flush(total_rt)
+        assert self.entered == self.exit_entered, (self.entered, self.exit_entered)
+        e.emit("s_waitcnt lgkmcnt(0)")
+        return e.lines
+
+
+def emit_pass(name, table, layers, nq_pass, units_pass, cfg, out):
+    nchunk = (units_pass + 15) // 16
+    padc = (nchunk + SLOTS - 1) // SLOTS * SLOTS
+    gen = PassGen(table, layers, nq_pass, padc, cfg)
+    lines = gen.generate()
+    stats = {}
+    for l in lines:
+        k = l.split()[0]
+        stats[k] = stats.get(k, 0) + 1
+    out.append("// pass %s: %d groups, %d layers; %d instructions; %s" % (
+        name, nq_pass, len(layers), len(lines), ", ".join("%s %d" % kv for kv in sorted(stats.items(), key=lambda kv: -kv[1])[:12])))
+    out.append("// keep[0..5] = Ph[0], Ph[1], Pl[0], Pl[1], Dh, Dl (the encodings' fp16 hi / lo B fragments) in v16..v39; sigma (lanes 0..15)")
+    out.append("// and rows 0..2 of the colour head's accumulator come back in v12..v15.  The reader must have run enter<0, NQ>().")
+    out.append("template <class Reader>")
+    out.append("__device__ __forceinline__ void mx_asm_%s(Reader& rd, lds_cptr bias_lane, lds_cptr rs_lane, half8 (&keep)[6], float& sigma, float (&rgb)[3]) {" % name)
+    out.append("    static_assert(Reader::DEPTH == 1 && Reader::Ring::STAG == 0, \"the asm streams take over a DEPTH-1 reader\");")
+    out.append("    const unsigned src_lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)rd.ring.src[0]), src_hi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)rd.ring.src[0] >> 32));")
+    out.append("    const unsigned nxt_lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)rd.ring.next), nxt_hi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)rd.ring.next >> 32));")
+    out.append("    const unsigned ldsw = __builtin_amdgcn_readfirstlane((unsigned)(size_t)TGTC_LPTR(rd.ring.lds_wave));")
+    out.append("    v16u wu = mx_cat4(rd.ub[0][0], rd.ub[0][1], rd.ub[0][2], rd.ub[0][3]);")
+    out.append("    u6v wl = rd.wb[0][0], wh = rd.wb[0][1];")
+
+    def rg(base, n):
+        return "{v[%d:%d]}" % (base, base + n - 1)
+    outs = ['"=&{v%d}"(sigma)' % OUT_SIG] + ['"=&{v%d}"(rgb[%d])' % (OUT_RGB + i, i) for i in range(3)]
+    outs += ['"+%s"(wu)' % rg(R.W0, 16), '"+%s"(wl)' % rg(R.W0 + 16, 6), '"+%s"(wh)' % rg(R.W0 + 22, 6)]
+    outs += ['"+%s"(keep[%d])' % (rg(16 + 4 * i, 4), i) for i in range(6)]
+    out.append("    asm volatile(")
+    out.append(block_text(lines))
+    ins = ['[lane_lo] "v"(rd.ring.lane_lo)', '[lane_hi] "v"(rd.ring.lane_hi)', '[b8_lo] "v"(rd.b8_lo)', '[b8_hi] "v"(rd.b8_hi)',
+           '[bias_lane] "v"(bias_lane)', '[rs_lane] "v"(rs_lane)', '[voff] "v"(rd.ring.voff)',
+           '[src_lo] "s"(src_lo)', '[src_hi] "s"(src_hi)', '[nxt_lo] "s"(nxt_lo)', '[nxt_hi] "s"(nxt_hi)', '[ldsw] "s"(ldsw)']
+    clob = ['"memory"', '"scc"', '"m0"', '"s96"', '"s97"']
+    owned = list(range(R.T, R.W0)) + list(range(R.W1, R.W1 + 28))
+    clob += ['"v%d"' % v for v in owned]
+    out.append("        : " + ", ".join(outs))
+    out.append("        : " + ", ".join(ins))
+    out.append("        : " + ", ".join(clob) + ");")
+    out.append("}")
+    out.append("")
+
+
 def block_text(lines):
     return "\n".join('        "%s\\n\\t"' % l for l in lines)
 
@@ -438,6 +726,7 @@ def main():
             emit_block("nerf_%s_l6_7" % tag, t, t.first[6], 2, bias0[6], nq, units, cfg, out)
             if full:
                 emit_block("nerf_%s_l9" % tag, t, t.first[9], 1, bias0[9], nq, units, cfg, out)
+                emit_pass("nerf_full_pass", t, nerf_full_layers(), nq, units, cfg, out)
     print("\n".join(out))
 
 
