@@ -7,16 +7,21 @@ fern-shaped 400x400 frames (BASELINE.json config 2), one process per GPU.
         bench.py --gpus N --steps K --warmup W [--sharding frames|rays]
 
 A "step" of the headline = every rank renders ONE whole 400x400 frame (160 000 rays) of its own camera pose:
-on-device ray generation (+NDC warp), then ONE launch of the fused ray kernel (render_fused.hip: coarse depths ->
-PE + coarse NeRF MLP -> weights -> inverse-CDF fine sampling -> PE + fine NeRF MLP -> alpha compositing; a wavefront
-owns a ray, per-sample tensors never exist), then (N > 1) one RCCL all-gather of the [160000, 4] RGB+depth images.
+on-device ray generation (+NDC warp), then the library's render of those rays (tgtc_render_rays_plain: coarse depths ->
+PE + coarse NeRF MLP -> weights -> inverse-CDF fine sampling -> PE + fine NeRF MLP -> alpha compositing) -- for the default
+precision pair (coarse fp16x3 + fine fp16mx) the split path: seven launches, of which the fine pass (mlp_nerf_mx2.hip, the
+two-tile persistent kernel) and the coarse pass are 99.9 % of the time; for the other pairs ONE launch of the fused ray kernel
+(render_fused.hip: a wavefront owns a ray, per-sample tensors never exist) -- then (N > 1) one RCCL all-gather of the
+[160000, 4] RGB+depth images.
 Per-GPU work is fixed as N grows (weak scaling); `value` = N * 160000 * steps / max-over-ranks wall time.
 `--sharding rays` (BASELINE config 4, strong scaling): every step renders ONE frame, each rank a contiguous 1/N of
 its rays (parallel.shard_range), reassembled by the same all-gather; `value` = 160000 * steps / time.
 Inputs resident in HBM when the timed region starts: packed weights, camera poses.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      the fused ray kernel, timed live with HIP events on the launch stream around every timed step
+  roofline      the dominant kernel, timed live with HIP events on the launch stream: split path = the fine pass's kernel on the
+                frame's ray count (launched again after the timed region); fused path = the ray kernel around every timed step.
+                `whole_render` prices all launches of a frame together, as rounds 1-3 priced the fused kernel
   cpu_baseline  the CPU oracle on the host cores (N = 1 only; bounded sample)
   configs       N = 1 only: BASELINE configs 3 and 4 on this GPU -- the stylised ray path, the 2-D style pass,
                 and a whole 504x378 trex frame -- each with its own live-timed value
@@ -351,7 +356,8 @@ def run_headline(args, precision, rank, world, dist):
     """The timed headline run; returns the JSON dict on rank 0, None elsewhere."""
     from tgtc_style_amd import parallel, synth, utils
     renderer = make_renderer(precision, False)
-    fused = renderer.fused and renderer._fused_shape(N_COARSE, N_FINE)
+    split = renderer.fused is True and renderer._split_is_faster()     # the library's choice for fp16x3 + fp16mx (include/tgtc_hip.h)
+    fused = renderer.fused and renderer._fused_shape(N_COARSE, N_FINE) and not split
     focal = synth.fern_intrinsics(H, W)
     n_rays = H * W
     by_rays = args.sharding == "rays" and world > 1
@@ -404,18 +410,45 @@ def run_headline(args, precision, rank, world, dist):
     if rank != 0:
         return None
 
-    kernel_ms = timed.mean_ms()
+    render_ms = timed.mean_ms()
     rays_total = (1 if by_rays else world) * n_rays * args.steps
     rays_launch = hi - lo
-    flop_launch = float(FLOP_PER_RAY) * rays_launch
-    achieved = flop_launch / (kernel_ms * 1e-3) / 1e12
     pf = precision.split("+")[-1]
-    kname = "fused_render_kernel" if fused else "per-sample kernel chain"
-    traffic, provenance = pmc_traffic("fused_render_kernel:%s" % precision) if fused else (None, "chain: not profiled")
+    whole = {"ms": render_ms, "achieved": float(FLOP_PER_RAY) * rays_launch / (render_ms * 1e-3) / 1e12,
+             "mfma_products_per_algorithmic_product": mfma_per_product(precision)}
+    whole["frac"] = whole["achieved"] / PEAK_FP16_TFLOPS
+    whole["mfma_pipe_frac"] = whole["frac"] * whole["mfma_products_per_algorithmic_product"]
+    if split:
+        # the dominant kernel of the split path: the fine pass (192 depths per ray, full network) on the two-tile per-sample
+        # kernel -- ONE launch per frame, timed live here on the launch stream with the frame's ray count
+        from tgtc_style_amd import hip
+        o, d = utils.gen_rays(H, W, focal, synth.spiral_pose(0), first_pixel=lo, n=hi - lo)
+        n_all = N_COARSE + N_FINE
+        ts = torch.linspace(0., 1., n_all, device="cuda").expand(rays_launch, n_all).contiguous()
+        rgb_s, sig_s = torch.empty(rays_launch * n_all, 3, device="cuda"), torch.empty(rays_launch * n_all, device="cuda")
+        lib, handle = hip.load(), renderer.fine.packed().handle
+        fine_pass = lambda i: hip.check(lib.tgtc_nerf_forward_rays(handle, hip.ptr(o), hip.ptr(d), hip.ptr(ts), rays_launch, n_all,
+                                                                   hip.ptr(rgb_s), hip.ptr(sig_s), hip.stream()))
+        _, kernel_ms, _ = time_loop(fine_pass, max(args.steps, 3), 1)
+        flop_launch = 2.0 * MAC_FULL * rays_launch * n_all
+        kname = ("nerf_mx2_kernel (the fine pass of %d rays in one launch: PE + full NeRF MLP on %d depths per ray; the frame's other "
+                 "launches: ray generation, coarse depths, coarse MLP (fp16x3, sigma only), two composites, fine sampling -- "
+                 "`whole_render` is all of them)" % (rays_launch, n_all))
+        traffic, provenance = pmc_traffic("nerf_mx2_kernel")
+        algo_bytes = rays_launch * (2 * 3 * 8 + n_all * 4 + n_all * 16)      # rays + depths in, rgb + sigma per sample out
+        prod = MFMA_PER_PRODUCT["fp16mx"]
+    else:
+        kernel_ms = render_ms
+        flop_launch = float(FLOP_PER_RAY) * rays_launch
+        kname = ("%s (whole render of %d rays in one launch: PE + coarse MLP x128, fine sampling, PE + fine MLP x192, compositing)"
+                 % ("fused_render_kernel" if fused else "per-sample kernel chain", rays_launch))
+        traffic, provenance = pmc_traffic("fused_render_kernel:%s" % precision) if fused else (None, "chain: not profiled")
+        algo_bytes = rays_launch * BYTES_PER_RAY
+        prod = mfma_per_product(precision)
+    achieved = flop_launch / (kernel_ms * 1e-3) / 1e12
     if traffic and rays_launch != n_rays:   # the PMC pass profiled whole-frame launches; a ray range streams in proportion
         traffic *= rays_launch / n_rays
         provenance += "; scaled by %d / %d rays of this launch" % (rays_launch, n_rays)
-    algo_bytes = rays_launch * BYTES_PER_RAY
     return {
         "metric": "rays/sec (128c+64f samples) on fern 400x400",
         "value": rays_total / dt,
@@ -435,16 +468,17 @@ def run_headline(args, precision, rank, world, dist):
                    "rays_per_step": (1 if by_rays else world) * n_rays, "precision": precision,
                    "sharding": "rays" if by_rays else "frames", "algorithmic_mflop_per_ray": FLOP_PER_RAY / 1e6,
                    "precision_note": NOTES.get(precision, "")},
-        "roofline": {"bound": "mfma",
-                     "kernel": "%s (whole render of %d rays in one launch: PE + coarse MLP x128, fine sampling, PE + fine MLP x192, "
-                               "compositing)" % (kname, rays_launch),
+        "roofline": {"bound": "mfma", "kernel": kname,
                      "achieved": achieved, "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP16_TFLOPS,
                      "traffic": traffic, "traffic_source": provenance,
                      "algorithmic_bytes_per_launch": algo_bytes,
                      "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
                      "kernel_ms": kernel_ms, "algorithmic_tflop_per_launch": flop_launch / 1e12,
-                     "mfma_products_per_algorithmic_product": mfma_per_product(precision),
-                     "mfma_pipe_frac": achieved * mfma_per_product(precision) / PEAK_FP16_TFLOPS},
+                     "mfma_products_per_algorithmic_product": prod,
+                     "mfma_pipe_frac": achieved * prod / PEAK_FP16_TFLOPS},
+        # every launch of one frame's render together (what `value` is made of), priced like rounds 1-3 priced the fused kernel
+        "whole_render": whole,
+        "render_path": "split (per-sample kernels; fine pass on the two-tile kernel)" if split else ("fused ray kernel" if fused else "per-sample kernel chain"),
         "whole_path_tflops": rays_total / dt * FLOP_PER_RAY / 1e12,
     }
 

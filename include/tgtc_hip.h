@@ -127,7 +127,11 @@ int tgtc_sample_fine(const double* rays_o, const double* rays_d, const float* ts
  *   - the coarse image is not requested (rgb_coarse == t_coarse == NULL);
  * then `workspace` is not touched and may be NULL.  Otherwise it falls back to
  * tgtc_render_rays_plain_chain: the same arithmetic as a sequence of per-sample kernels through
- * workspace (device scratch of at least tgtc_render_workspace_bytes(R, n_coarse, n_fine) bytes). */
+ * workspace (device scratch of at least tgtc_render_workspace_bytes(R, n_coarse, n_fine) bytes).
+ * One pair takes the chain by choice: fp16x3 (coarse) + fp16_fp6 (fine) with a sufficient workspace handed over -- its fine
+ * pass runs ~10 % faster on the two-tile per-sample kernel (csrc/mlp_nerf_mx2.hip) than inside the ray kernel, and the
+ * per-sample tensors cost 0.3 % of the frame in HBM traffic.  tgtc_render_rays_plain_fused is the single kernel and
+ * nothing else (TGTC_ERR_UNSUPPORTED outside the conditions above). */
 size_t tgtc_render_workspace_bytes(int64_t R, int n_coarse, int n_fine);
 int tgtc_render_rays_plain(const tgtc_net* coarse, const tgtc_net* fine, const double* rays_o, const double* rays_d,
                            int64_t R, int n_coarse, int n_fine, float near_, float far_, const float* jitter,
@@ -137,6 +141,9 @@ int tgtc_render_rays_plain_chain(const tgtc_net* coarse, const tgtc_net* fine, c
                                  const double* rays_d, int64_t R, int n_coarse, int n_fine, float near_, float far_,
                                  const float* jitter, void* workspace, size_t workspace_bytes, float* rgb_fine,
                                  float* t_fine, float* rgb_coarse, float* t_coarse, void* stream);
+int tgtc_render_rays_plain_fused(const tgtc_net* coarse, const tgtc_net* fine, const double* rays_o,
+                                 const double* rays_d, int64_t R, int n_coarse, int n_fine, float near_, float far_,
+                                 const float* jitter, float* rgb_fine, float* t_fine, void* stream);
 
 /* ------------------------------------------------------------------ a8: latent table
  * models.py:490-506 StyleLatents_variational.forward.  latents float [S,F,D] device, mu float [S,D] device,

@@ -35,7 +35,8 @@ def renderer(prec_c, prec_f, fused):
         m = models.StyleNerf(type("A", (Args,), {"precision": prec}), mode=mode)
         m.load_state_dict(T(synth.nerf_state(seed)))
         nets.append(m.cuda())
-    return rendering.RayRenderer(nets[0], nets[1], fused=fused)
+    # (True here means THE single kernel: RayRenderer's own True lets the library pick, and for fp16x3 + fp16mx it picks the split path)
+    return rendering.RayRenderer(nets[0], nets[1], fused="single" if fused is True else fused)
 
 
 PAIRS = [("fp16x3", "fp16x3"), ("fp16x3", "fp16mx"), ("fp16", "fp16")]
@@ -66,6 +67,23 @@ def test_fused_render_golden(golden, prec_c, prec_f, nc, nf):
         assert e_ref <= LIMIT[prec_f] and e_chain <= VS_CHAIN[prec_f]
 
 
+def test_default_path_of_the_headline_pair_is_the_split_path(golden):
+    """RayRenderer(fused=True) hands the workspace over for coarse fp16x3 + fine fp16mx and the library renders through the
+    per-sample kernels (fine pass: the two-tile kernel, mlp_nerf_mx2.hip): the same bits as the forced chain; 'single' still
+    reaches the ray kernel and agrees to the fused-vs-chain tolerance."""
+    from tgtc_style_amd import rendering
+    g = golden("g8_end_to_end")
+    ro, rd = torch.from_numpy(g["rays_o_128c64f"]).cuda(), torch.from_numpy(g["rays_d_128c64f"]).cuda()
+    single, chain = renderer("fp16x3", "fp16mx", True), renderer("fp16x3", "fp16mx", False)
+    auto = rendering.RayRenderer(chain.coarse, chain.fine)
+    assert auto._split_is_faster() and auto.fused is True
+    a, b, c = auto.render(ro, rd, 128, 64), chain.render(ro, rd, 128, 64), single.render(ro, rd, 128, 64)
+    assert torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["t"], b["t"])
+    assert float((a["rgb"] - c["rgb"]).abs().max()) <= VS_CHAIN["fp16mx"]
+    with pytest.raises(ValueError):
+        rendering.RayRenderer(chain.coarse, chain.fine, fused="single").render(ro, rd, 128, 64, want_coarse=True)
+
+
 @pytest.mark.parametrize("prec_c,prec_f", PAIRS)
 def test_fused_render_ray_counts_and_shards(prec_c, prec_f):
     from tgtc_style_amd import utils
@@ -88,7 +106,11 @@ def test_fused_falls_back_to_the_chain():
     """Sample counts the ray kernel does not tile (n_coarse not a multiple of 16) and requests for the coarse image run
     the per-sample chain behind the same entry point."""
     from tgtc_style_amd import utils
-    r = renderer("fp16x3", "fp16x3", True)
+    from tgtc_style_amd import rendering
+    single = renderer("fp16x3", "fp16x3", True)
+    r = rendering.RayRenderer(single.coarse, single.fine)
+    with pytest.raises(ValueError):
+        single.render(*utils.gen_rays(4, 4, synth.fern_intrinsics(4, 4), synth.spiral_pose(1)), 100, 28)
     assert not r._fused_shape(100, 28) and r._fused_shape(128, 64) and not r._fused_shape(208, 48)
     ro, rd = utils.gen_rays(16, 16, synth.fern_intrinsics(16, 16), synth.spiral_pose(1))
     a = r.render(ro, rd, 100, 28)

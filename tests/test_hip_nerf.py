@@ -149,6 +149,47 @@ def test_fp16mx_dynamic_range(log2_range, bound):
     assert max(errs.values()) <= bound, errs
 
 
+@pytest.mark.parametrize("M", [1, 31, 128, 129, 1000, 70001])
+def test_two_tile_fp16mx_kernel_matches_the_one_tile_kernel_bit_for_bit(M):
+    """tgtc_nerf_forward in fp16mx without the base_remap output runs the persistent two-tile kernel (csrc/mlp_nerf_mx2.hip: one
+    generated instruction stream per pass, 128 samples per workgroup and pass, tools/gen_mx2_asm.py); with it, the one-tile
+    kernel (mlp_nerf_mx.hip).  Same arithmetic per sample in the same order: the same bits, for any sample count (tails of a
+    pass, of a tile, fewer passes than CUs, several passes per workgroup) and both input modes."""
+    from tgtc_style_amd import hip
+    lib = hip.load()
+    rng = np.random.default_rng(M)
+    pts = torch.from_numpy(rng.uniform(-1.5, 1.5, (M, 3))).cuda()
+    dirs = torch.from_numpy(rng.uniform(-1, 1, (M, 3))).cuda()
+    net = make_nerf(1, "fine", "fp16mx")
+    h = net.packed().handle
+    out = {}
+    for tag in ("two_tile", "one_tile"):
+        rgb = torch.full((M, 3), -7.0, device="cuda")
+        sigma = torch.full((M,), -7.0, device="cuda")
+        remap = torch.empty(M, 256, device="cuda") if tag == "one_tile" else None
+        hip.check(lib.tgtc_nerf_forward(h, hip.ptr(pts), hip.ptr(dirs), M, hip.ptr(rgb), hip.ptr(sigma), hip.ptr(remap), None, None, hip.stream()))
+        out[tag] = (rgb, sigma)
+    assert torch.equal(out["two_tile"][0], out["one_tile"][0]) and torch.equal(out["two_tile"][1], out["one_tile"][1])
+    ref = fields.style_nerf(T(synth.nerf_state(1)), pts.cpu(), dirs.cpu())
+    assert rel(out["two_tile"][0].cpu(), ref["rgb"]) <= 1e-3 and rel(out["two_tile"][1].cpu(), ref["sigma"]) <= 1e-3
+    # rays as input (the render chain's fine pass)
+    R, N = max(M // 192, 1), 192
+    ro = torch.from_numpy(rng.uniform(-0.3, 0.3, (R, 3))).cuda()
+    rd = torch.from_numpy(rng.uniform(-1, 1, (R, 3))).cuda()
+    ts = torch.sort(torch.from_numpy(rng.uniform(0, 1, (R, N)).astype(np.float32)).cuda(), -1).values.contiguous()
+    rgb = torch.empty(R * N, 3, device="cuda")
+    sigma = torch.empty(R * N, device="cuda")
+    hip.check(lib.tgtc_nerf_forward_rays(h, hip.ptr(ro), hip.ptr(rd), hip.ptr(ts), R, N, hip.ptr(rgb), hip.ptr(sigma), hip.stream()))
+    p = (ro[:, None, :] + ts.double()[:, :, None] * rd[:, None, :]).reshape(-1, 3)
+    rgb2 = torch.empty(R * N, 3, device="cuda")
+    sigma2 = torch.empty(R * N, device="cuda")
+    remap = torch.empty(R * N, 256, device="cuda")
+    hip.check(lib.tgtc_nerf_forward(h, hip.ptr(p.contiguous()), hip.ptr(rd[:, None, :].expand(R, N, 3).reshape(-1, 3).contiguous()), R * N,
+                                    hip.ptr(rgb2), hip.ptr(sigma2), hip.ptr(remap), None, None, hip.stream()))
+    # (positions: the kernel forms o + t d itself, possibly with one fused rounding less than torch: equal to fp16mx's own noise)
+    assert rel(rgb, rgb2.cpu()) <= 2e-4 and rel(sigma, sigma2.cpu()) <= 2e-4
+
+
 def test_repack_on_weight_change():
     m = make_nerf(0, "coarse", "fp16x3")
     pts = torch.from_numpy(np.random.default_rng(0).uniform(-1, 1, (64, 3))).cuda()

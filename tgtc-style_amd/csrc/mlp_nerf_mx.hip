@@ -206,8 +206,14 @@ int nerf_mx_pack(const tgtc_linear* layers, std::vector<char>& bias_region, std:
     return TGTC_OK;
 }
 
+// 1 (shipped): FULL launches that do not ask for base_remap go to the two-tile persistent kernel (mlp_nerf_mx2.hip)
+#ifndef TGTC_MX2
+#define TGTC_MX2 1
+#endif
+
 int nerf_mx_launch(int in_mode, bool full, const NerfArgs& a, hipStream_t st) {
     using C = CfgMx;
+    if (TGTC_MX2 && full && !a.remap) return nerf_mx2_launch(in_mode, a, st);
     const unsigned nwg = (unsigned)((a.M + C::SAMPLES_PER_WG - 1) / C::SAMPLES_PER_WG);
     const dim3 block(C::NWAVES * 64);
     switch (in_mode * 2 + (full ? 1 : 0)) {

@@ -54,6 +54,19 @@ extern "C" size_t tgtc_render_workspace_bytes(int64_t R, int n_coarse, int n_fin
 // The plain render.  Whenever the sample counts and precisions allow it (and the caller does not ask for the coarse
 // image) this is ONE launch of the fused ray kernel (render_fused.hip) and the workspace is not touched; otherwise
 // the chain of per-sample kernels below runs (tgtc_render_rays_plain_chain, always available).
+extern "C" int tgtc_render_rays_plain_fused(const tgtc_net* coarse, const tgtc_net* fine, const double* rays_o,
+                                            const double* rays_d, int64_t R, int n_coarse, int n_fine, float near_,
+                                            float far_, const float* jitter, float* rgb_fine, float* t_fine, void* stream) {
+    TGTC_REQUIRE(coarse && fine && R >= 0, "render_rays_plain_fused: bad argument");
+    if (!(coarse->kind == 0 && fine->kind == 0 && fused_render_supports(coarse->precision, fine->precision, n_coarse, n_fine)))
+        return fail(TGTC_ERR_UNSUPPORTED, "render_rays_plain_fused: no single-kernel build for precisions %d + %d with %d + %d samples",
+                    coarse->precision, fine->precision, n_coarse, n_fine);
+    if (R == 0) return TGTC_OK;
+    TGTC_REQUIRE(rays_o && rays_d && rgb_fine && t_fine, "render_rays_plain_fused: null pointer");
+    FusedArgs a{rays_o, rays_d, R, n_coarse, n_fine, near_, far_, jitter, coarse->dev, fine->dev, rgb_fine, t_fine, nullptr};
+    return launch_fused_render(coarse->precision, fine->precision, a, as_stream(stream));
+}
+
 extern "C" int tgtc_render_rays_plain(const tgtc_net* coarse, const tgtc_net* fine, const double* rays_o,
                                       const double* rays_d, int64_t R, int n_coarse, int n_fine, float near_,
                                       float far_, const float* jitter, void* workspace, size_t workspace_bytes,
@@ -62,10 +75,13 @@ extern "C" int tgtc_render_rays_plain(const tgtc_net* coarse, const tgtc_net* fi
     TGTC_REQUIRE(coarse && fine && R >= 0, "render_rays_plain: bad argument");
     if (!rgb_coarse && !t_coarse && coarse->kind == 0 && fine->kind == 0 &&
         fused_render_supports(coarse->precision, fine->precision, n_coarse, n_fine)) {
-        if (R == 0) return TGTC_OK;
-        TGTC_REQUIRE(rays_o && rays_d && rgb_fine && t_fine, "render_rays_plain: null pointer");
-        FusedArgs a{rays_o, rays_d, R, n_coarse, n_fine, near_, far_, jitter, coarse->dev, fine->dev, rgb_fine, t_fine, nullptr};
-        return launch_fused_render(coarse->precision, fine->precision, a, as_stream(stream));
+        // fp16x3 + fp16_fp6: the fine pass is faster on the two-tile per-sample kernel (mlp_nerf_mx2.hip: half the LDS bytes per
+        // MFMA of any one-tile loop, the ray kernel's included) than inside the ray kernel, and the per-sample tensors it
+        // needs are 0.3 % of the frame time in HBM traffic: a caller that hands over the workspace gets the split path
+        const bool split_is_faster = coarse->precision == TGTC_PREC_FP16X3 && fine->precision == TGTC_PREC_FP16_FP6 && workspace &&
+                                     workspace_bytes >= tgtc_render_workspace_bytes(R, n_coarse, n_fine);
+        if (!split_is_faster)
+            return tgtc_render_rays_plain_fused(coarse, fine, rays_o, rays_d, R, n_coarse, n_fine, near_, far_, jitter, rgb_fine, t_fine, stream);
     }
     return tgtc_render_rays_plain_chain(coarse, fine, rays_o, rays_d, R, n_coarse, n_fine, near_, far_, jitter, workspace,
                                         workspace_bytes, rgb_fine, t_fine, rgb_coarse, t_coarse, stream);

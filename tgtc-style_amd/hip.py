@@ -54,6 +54,8 @@ _SIGNATURES = {
                                c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "tgtc_render_rays_plain_chain": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float,
                                      c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "tgtc_render_rays_plain_fused": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float,
+                                     c_void_p, c_void_p, c_void_p, c_void_p],
     "tgtc_image_epilogue": [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p],
     "tgtc_latents_forward": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_float, c_int,
                              c_void_p, c_void_p],

@@ -23,11 +23,20 @@ class RayRenderer:
     """
 
     def __init__(self, coarse, fine, style=None, fused=True):
-        """fused=False forces the chain of per-sample kernels (tgtc_render_rays_plain_chain / tgtc_render_rays_styled_chain)
-        where the library would otherwise run a single persistent ray kernel; results agree to rounding
-        (tests/test_fused_gpu.py)."""
+        """fused=True: the library's fastest path -- a single persistent ray kernel where one is built, except for coarse
+        fp16x3 + fine fp16mx, whose fine pass runs faster on the two-tile per-sample kernel (include/tgtc_hip.h,
+        tgtc_render_rays_plain: the split path, taken when the workspace is handed over).  fused="single" asks for the single
+        kernel and nothing else (tgtc_render_rays_plain_fused; plain renders only).  fused=False forces the chain of
+        per-sample kernels (tgtc_render_rays_plain_chain / tgtc_render_rays_styled_chain).  All three agree to rounding, the
+        network arithmetic bit for bit (tests/test_fused_gpu.py)."""
+        if fused not in (True, False, "single"):
+            raise ValueError("fused must be True, False or 'single'")
         self.coarse, self.fine, self.style, self.fused = coarse, fine, style, fused
         self._ws = None
+
+    def _split_is_faster(self):
+        """Mirror of the library's rule (csrc/render.hip, tgtc_render_rays_plain)."""
+        return (self.coarse.packed().precision, self.fine.packed().precision) == ("fp16x3", "fp16mx")
 
     def _fused_shape(self, nc, nf):
         """Mirror of the library's rule (include/tgtc_hip.h, tgtc_render_rays_plain): when it renders with the single
@@ -60,6 +69,11 @@ class RayRenderer:
         plain = self.style is None or z is None
         one_kernel = self.fused and not want_coarse and (self._fused_shape(n_coarse, n_fine) if plain else
                                                          self._fused_styled_shape(n_coarse, n_fine))
+        if self.fused == "single":
+            if not (plain and one_kernel):
+                raise ValueError("fused='single': no single-kernel build for this render (precisions, sample counts, coarse image or style)")
+        elif one_kernel and plain and self._split_is_faster():
+            one_kernel = False              # hand the workspace over: the library takes the split path
         ws = None if one_kernel else self._workspace(R, n_coarse, n_fine, dev)
         rgb = torch.empty(R, 3, device=dev, dtype=torch.float32)
         t = torch.empty(R, device=dev, dtype=torch.float32)
@@ -67,7 +81,11 @@ class RayRenderer:
         t_c = torch.empty(R, device=dev, dtype=torch.float32) if want_coarse else None
         if jitter is not None:
             jitter = jitter.to(torch.float32).contiguous()
-        if plain:
+        if plain and self.fused == "single":
+            hip.check(lib.tgtc_render_rays_plain_fused(self.coarse.packed().handle, self.fine.packed().handle, hip.ptr(rays_o),
+                                                       hip.ptr(rays_d), R, n_coarse, n_fine, float(near), float(far), hip.ptr(jitter),
+                                                       hip.ptr(rgb), hip.ptr(t), hip.stream()))
+        elif plain:
             fn = lib.tgtc_render_rays_plain if self.fused else lib.tgtc_render_rays_plain_chain
             hip.check(fn(self.coarse.packed().handle, self.fine.packed().handle, hip.ptr(rays_o), hip.ptr(rays_d), R,
                          n_coarse, n_fine, float(near), float(far), hip.ptr(jitter), hip.ptr(ws),

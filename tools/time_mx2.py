@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Development timing: ONE launch of the fine pass's per-sample kernel over a whole 400x400 frame (160 000 rays x 192 depths,
+tgtc_nerf_forward_rays, fp16mx), i.e. nerf_mx2_kernel (product) or nerf_mx_kernel (-DTGTC_MX2=0 builds)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from tgtc_style_amd import hip, synth, utils
+H = W = 400
+N = 192
+o, d = utils.gen_rays(H, W, synth.fern_intrinsics(H, W), synth.spiral_pose(0))
+o, d = o.contiguous(), d.contiguous()
+R = o.shape[0]
+ts = torch.linspace(0., 1., N, device="cuda").expand(R, N).contiguous()
+_, fine = bench.build_nets("fp16x3+fp16mx")
+rgb = torch.empty(R * N, 3, device="cuda")
+sigma = torch.empty(R * N, device="cuda")
+lib = hip.load()
+call = lambda: hip.check(lib.tgtc_nerf_forward_rays(fine.packed().handle, hip.ptr(o), hip.ptr(d), hip.ptr(ts), R, N, hip.ptr(rgb), hip.ptr(sigma), hip.stream()))
+for _ in range(2):
+    call()
+torch.cuda.synchronize()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+ev[0].record()
+for _ in range(4):
+    call()
+ev[1].record()
+torch.cuda.synchronize()
+ms = ev[0].elapsed_time(ev[1]) / 4
+flop = 2.0 * bench.MAC_FULL * R * N
+print("fine pass kernel %7.2f ms   %.1f TFLOP/s algorithmic   matrix pipe %.3f   checksum %.6e %.6e" % (
+    ms, flop / ms / 1e9, flop * 1.5 / (ms * 1e-3) / 2.5e15, float(rgb.double().sum()), float(sigma.double().sum())), flush=True)
