@@ -190,6 +190,30 @@ def test_two_tile_fp16mx_kernel_matches_the_one_tile_kernel_bit_for_bit(M):
     assert rel(rgb, rgb2.cpu()) <= 2e-4 and rel(sigma, sigma2.cpu()) <= 2e-4
 
 
+@pytest.mark.parametrize("R,N", [(1, 16), (3, 128), (40, 128), (700, 128), (257, 64), (2200, 128)])
+def test_two_tile_fp16x3_sigma_kernel_matches_the_one_tile_kernel_bit_for_bit(R, N):
+    """tgtc_nerf_forward_rays in fp16x3 with sigma as the only output (the coarse pass of a render) runs the persistent two-tile
+    kernel (csrc/mlp_nerf_x3s.hip: one generated instruction stream per pass, tools/gen_x3_asm.py); asked for the colour too, the
+    one-tile kernel (mlp_nerf.hip).  Same trunk arithmetic per sample in the same order: the same density bits for any ray and
+    sample count (tails of a pass and of a tile, fewer passes than CUs, several passes per workgroup)."""
+    from tgtc_style_amd import hip
+    lib = hip.load()
+    rng = np.random.default_rng(R * 1000 + N)
+    ro = torch.from_numpy(rng.uniform(-0.3, 0.3, (R, 3))).cuda()
+    rd = torch.from_numpy(rng.uniform(-1, 1, (R, 3))).cuda()
+    ts = torch.sort(torch.from_numpy(rng.uniform(0, 1, (R, N)).astype(np.float32)).cuda(), -1).values.contiguous()
+    net = make_nerf(0, "coarse", "fp16x3")
+    h = net.packed().handle
+    s_new = torch.full((R * N,), -7.0, device="cuda")
+    hip.check(lib.tgtc_nerf_forward_rays(h, hip.ptr(ro), hip.ptr(rd), hip.ptr(ts), R, N, None, hip.ptr(s_new), hip.stream()))
+    s_old, rgb = torch.full((R * N,), -7.0, device="cuda"), torch.empty(R * N, 3, device="cuda")
+    hip.check(lib.tgtc_nerf_forward_rays(h, hip.ptr(ro), hip.ptr(rd), hip.ptr(ts), R, N, hip.ptr(rgb), hip.ptr(s_old), hip.stream()))
+    assert torch.equal(s_new, s_old)
+    pts = (ro[:, None, :] + ts.double()[:, :, None] * rd[:, None, :]).reshape(-1, 3).cpu()
+    ref = fields.style_nerf(T(synth.nerf_state(0)), pts, rd[:, None, :].expand(R, N, 3).reshape(-1, 3).cpu())
+    assert rel(s_new.cpu(), ref["sigma"]) <= 5e-5
+
+
 def test_repack_on_weight_change():
     m = make_nerf(0, "coarse", "fp16x3")
     pts = torch.from_numpy(np.random.default_rng(0).uniform(-1, 1, (64, 3))).cuda()

@@ -258,6 +258,11 @@ TGTC_NERF_FP16_INSTANCES()
 TGTC_NERF_FP16_INSTANCES(extern)
 #endif
 
+// 1 (shipped): sigma-only fp16x3 launches over rays (the coarse pass of a render) go to the two-tile persistent kernel (mlp_nerf_x3s.hip)
+#ifndef TGTC_X3S
+#define TGTC_X3S 1
+#endif
+
 template <int IN_MODE, bool FULL>
 static int dispatch_nerf(const tgtc_net* net, NerfArgs& a, hipStream_t st) {
     a.bias = net->dev;
@@ -274,6 +279,12 @@ static int dispatch_nerf(const tgtc_net* net, NerfArgs& a, hipStream_t st) {
         return nerf_mx_launch(IN_MODE, FULL, a, st);
     }
     if (net->precision == TGTC_PREC_FP16) return launch_nerf<CfgFast, IN_MODE, FULL>(a, st);
+    if constexpr (TGTC_X3S && IN_MODE == IN_RAYS && !FULL) {   // the coarse pass: sigma only, no encodings out
+        if (a.sigma && !a.out_pts_enc && !a.out_dirs_enc) {
+            if (a.M >= 0x7fffffffLL) return fail(TGTC_ERR_UNSUPPORTED, "nerf: too many samples in one launch (%lld)", a.M);
+            return nerf_x3s_launch(a, st);
+        }
+    }
     return launch_nerf<CfgExact, IN_MODE, FULL>(a, st);
 #endif
 }

@@ -15,7 +15,7 @@ set -e
 cd "$(dirname "$0")/../tgtc-style_amd/csrc"
 TAG="$1"; EXTRA="$2"; shift 2 || true
 FILES="${@:-mlp_nerf_mx.hip render_fused.hip}"
-OBJS="common.o raypath.o mlp_nerf.o mlp_nerf_fp16.o mlp_nerf_mx.o mlp_nerf_mx2.o render.o render_fused.o render_styled_fused.o mlp_style.o mlp_style_fp16.o style2d.o mlp_train.o"
+OBJS="common.o raypath.o mlp_nerf.o mlp_nerf_fp16.o mlp_nerf_mx.o mlp_nerf_mx2.o mlp_nerf_x3s.o render.o render_fused.o render_styled_fused.o mlp_style.o mlp_style_fp16.o style2d.o mlp_train.o"
 pids=""
 for f in $FILES; do
   o=/tmp/${f%.hip}_$TAG.o

@@ -101,12 +101,14 @@ class Pass2:
         self.cfg = cfg or {}         # timing experiments (results wrong by construction): abl_epi, abl_reads, abl_ring, abl_barrier, abl_dma, abl_cvt
         self.e = Emitter()
         self.unit_op, self.unit_chunk = {}, {}
+        self.dma_q = []
         self.entered = -1
         self.exit_entered = max(table.chunk_hi(nq - 1) - 1, 0)
 
     # ------------------------------------------------------------------------------------------ ring
     def boundary(self, v):
         e = self.e
+        self.drain_dma(99)                   # (m0 and s[96:97] are about to change)
         victims = [op for op, ch in self.unit_chunk.items() if ch <= v - 1 and op >= e.lds_done]
         if victims:
             e.need(max(victims))
@@ -127,8 +129,17 @@ class Pass2:
         e.emit("s_add_u32 m0, %%[ldsw], 0x%x" % (slot * CHUNK))
         e.emit("s_nop 0")
         for j in range(GPC):
-            e.emit("global_load_lds_dwordx4 %%[voff], s[96:97] offset:%d" % (j * 1024))
+            line = "global_load_lds_dwordx4 %%[voff], s[96:97] offset:%d" % (j * 1024)
+            if self.cfg.get("spread_dma", 1):
+                self.dma_q.append(line)      # issued one per MFMA gap (drain_dma): four in a row hold the wave's issue for ~4 x 16 clocks
+            else:
+                e.emit(line)
         self.entered = v
+
+    def drain_dma(self, n=1):
+        while self.dma_q and n > 0:
+            self.e.emit(self.dma_q.pop(0))
+            n -= 1
 
     def acquire_for(self, q):
         g = min(q, self.nq - 1)
@@ -219,21 +230,28 @@ class Pass2:
             for i in range(4):
                 head.append(lambda i=i, a=a, t=t: e.emit("v_max_i32_e32 %s, 0, %s" % (V(t + i), V(a + i))))
             ops = body[ct]
+            stages = [[], [], [], []]        # per half: convert, lo half 0, running maximum, lo half 1 -- each reads the one before
             for half in range(2):
                 d = (rt & 1) * 2 + half
                 h = hreg(st, ct) + 4 * ks + d
                 lo = L16 + 16 * ct + 4 * (ks & 3) + d
                 t0, t1 = t + 2 * half, t + 2 * half + 1
                 mxk = MXK + ct
-                ops.append(lambda h=h, t0=t0, t1=t1: e.emit("v_cvt_pk_f16_f32 %s, %s, %s" % (V(h), V(t0), V(t1))))
-                ops.append(lambda lo=lo, t0=t0, h=h: e.emit(
+                stages[0].append(lambda h=h, t0=t0, t1=t1: e.emit("v_cvt_pk_f16_f32 %s, %s, %s" % (V(h), V(t0), V(t1))))
+                stages[1].append(lambda lo=lo, t0=t0, h=h: e.emit(
                     "v_fma_mixlo_f16 %s, %s, 1.0, -%s op_sel:[0,0,0] op_sel_hi:[0,0,1]" % (V(lo), V(t0), V(h))))
                 if (rt & 7) == 0 and half == 0:
-                    ops.append(lambda h=h, mxk=mxk: e.emit("v_mov_b32_e32 %s, %s" % (V(mxk), V(h))))
+                    stages[2].append(lambda h=h, mxk=mxk: e.emit("v_mov_b32_e32 %s, %s" % (V(mxk), V(h))))
                 else:
-                    ops.append(lambda h=h, mxk=mxk: e.emit("v_pk_max_u16 %s, %s, %s" % (V(mxk), V(mxk), V(h))))
-                ops.append(lambda lo=lo, t1=t1, h=h: e.emit(
+                    stages[2].append(lambda h=h, mxk=mxk: e.emit("v_pk_max_u16 %s, %s, %s" % (V(mxk), V(mxk), V(h))))
+                stages[3].append(lambda lo=lo, t1=t1, h=h: e.emit(
                     "v_fma_mixhi_f16 %s, %s, 1.0, -%s op_sel:[0,0,1] op_sel_hi:[0,0,1]" % (V(lo), V(t1), V(h))))
+            if self.cfg.get("reorder_epi"):  # both halves stage by stage (measured: no difference, profiles/r4_kernel_variants.md)
+                for stage in stages:
+                    ops.extend(stage)
+            else:
+                for half in range(2):
+                    ops.extend(stage[half] for stage in stages)
             if (rt & 7) == 7:
                 kb = rt // 8
                 m0, m1, m2, m3 = MS + 4 * ct, MS + 4 * ct + 1, MS + 4 * ct + 2, MS + 4 * ct + 3
@@ -384,6 +402,7 @@ class Pass2:
                 issue_ready()
                 for text, released in self.mfmas(g, L, s):
                     e.emit(text)
+                    self.drain_dma()
                     free[par] |= set(released)
                     issue_ready()
                     if gap >= 3 and fillers:
@@ -413,6 +432,7 @@ class Pass2:
         e.lds_done = e.lds_issued
         for v in range(self.entered + 1, self.padc):
             self.boundary(v)
+        self.drain_dma(99)
         return e.lines
 
 
