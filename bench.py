@@ -327,7 +327,9 @@ def make_renderer(precision, styled):
         cm.load_state_dict(t_state(synth.concat_state(2)))
         sm.load_state_dict(t_state(synth.style_state(3)))
         style = models.StylePair(cm.cuda(), sm.cuda())
-    return rendering.RayRenderer(coarse, fine, style, fused=not os.environ.get("TGTC_BENCH_CHAIN"))
+    # (development: TGTC_BENCH_CHAIN forces the per-sample chain, TGTC_BENCH_SINGLE the single ray kernel where the library would split)
+    fused = False if os.environ.get("TGTC_BENCH_CHAIN") else ("single" if os.environ.get("TGTC_BENCH_SINGLE") and not styled else True)
+    return rendering.RayRenderer(coarse, fine, style, fused=fused)
 
 
 def bench_frame(precision, h, w, steps, warmup, styled=False):

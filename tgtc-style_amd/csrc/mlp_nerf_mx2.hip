@@ -27,8 +27,10 @@ __global__ void __launch_bounds__(256, 1) nerf_mx2_kernel(NerfArgs a, long long 
     using C = CfgMx2;
     constexpr int NUNITS = nerf_mx_units(true);
     using Reader = MxReader<C, SingleStreamMap<NUNITS>, kNerfMxTable, true>;
-    static_assert(Reader::Ring::PADC == kMx2PadChunks && C::GPC == 4 && C::SLOTS == 8 && kChunkBytes == 16384,
-                  "the generated stream was laid out for this ring");
+    // the stream's ring: 128 KiB in chunks of kMx2ChunkBytes (the generator's `chunk`), every wave moves 1/4 of a chunk
+    constexpr int kChunk = kMx2ChunkBytes, kSlots = C::RING_BYTES / kChunk, kLook = kSlots - 1, kPiece = kChunk / C::NWAVES;
+    constexpr int kPad = ((NUNITS * 1024 + kChunk - 1) / kChunk + kSlots - 1) / kSlots * kSlots;
+    static_assert(kPad == kMx2PadChunks && C::RING_BYTES == 131072 && kPiece % 4096 == 0, "the generated stream was laid out for this ring");
 
     // ring | biases + row exponents
     __shared__ __attribute__((aligned(16))) char smem[C::RING_BYTES + kNerfBiasBytes];
@@ -41,10 +43,14 @@ __global__ void __launch_bounds__(256, 1) nerf_mx2_kernel(NerfArgs a, long long 
 #pragma unroll
         for (int j = 0; j < kNerfBiasBytes / (C::NWAVES * 1024); ++j)
             lds_dma16(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16, smem + C::RING_BYTES + (j * C::NWAVES + wave) * 1024);
-        // chunks 0..6 of the stream: the state every pass's entry expects (the first entry's counted wait also covers the
-        // bias table: it is older than the chunks)
-        rd.ring.next = rd.ring.src[0];
-        rd.ring.persist_prologue();
+        // chunks 0 .. kLook-1 of the stream: the state every pass's entry expects (the first entry's counted wait also covers
+        // the bias table: it is older than the chunks)
+        rd.ring.lds_wave = smem + wave * kPiece;
+        rd.ring.voff = wave * kPiece + lane * 16;
+        static_for<kLook * (kPiece / 1024)>([&](auto i_) {
+            constexpr int i = decltype(i_)::value, ch = i / (kPiece / 1024), j = i % (kPiece / 1024);
+            lds_dma16_s<(j % 4) * 1024>(rd.ring.src[0] + ch * kChunk + (j / 4) * 4096, rd.ring.voff, rd.ring.lds_wave + ch * kChunk + (j / 4) * 4096);
+        });
     }
 
     for (long long p = blockIdx.x; p < n_pass; p += gridDim.x) {
@@ -72,6 +78,7 @@ __global__ void __launch_bounds__(256, 1) nerf_mx2_kernel(NerfArgs a, long long 
         // per-lane addresses from a lane id read HERE: nothing but them and the loop's scalars lives across the stream
         rd.relane(smem, wave);
         const int fl = fresh_lane_id();
+        rd.ring.voff = wave * kPiece + fl * 16;
         const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * (fl >> 4));
         const lds_cptr rs_lane = opaque((lds_cptr)smem + C::RING_BYTES + kNerfMxScaleOff + 2 * (fl & 15));
         float sigma[2], rgb[2][3];

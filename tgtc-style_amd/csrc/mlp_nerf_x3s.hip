@@ -20,8 +20,10 @@ using CfgX3s = MlpCfg<4, 2, true, 4>;
 __global__ void __launch_bounds__(256, 1) nerf_x3s_kernel(NerfArgs a, long long n_pass) {
     using C = CfgX3s;
     using Ring = WeightStream<C, SingleStreamMap<NerfLayout::kFragsSigma>, true, true>;
-    static_assert(NerfLayout::kFragsSigma == kX3sFrags && Ring::PADC == kX3sPadChunks && C::GPC == 4 && C::SLOTS == 8 &&
-                      kChunkBytes == 16384 && C::FRAG_BYTES == 2048,
+    // the stream's ring: 128 KiB in chunks of kX3sChunkBytes (the generator's `chunk`), every wave moves 1/4 of a chunk
+    constexpr int kChunk = kX3sChunkBytes, kSlots = C::RING_BYTES / kChunk, kLook = kSlots - 1, kPiece = kChunk / C::NWAVES;
+    constexpr int kPad = ((NerfLayout::kFragsSigma * C::FRAG_BYTES + kChunk - 1) / kChunk + kSlots - 1) / kSlots * kSlots;
+    static_assert(NerfLayout::kFragsSigma == kX3sFrags && kPad == kX3sPadChunks && C::RING_BYTES == 131072 && C::FRAG_BYTES == 2048 && kPiece % 4096 == 0,
                   "the generated stream was laid out for this ring");
 
     // ring | biases
@@ -35,10 +37,14 @@ __global__ void __launch_bounds__(256, 1) nerf_x3s_kernel(NerfArgs a, long long 
 #pragma unroll
         for (int j = 0; j < kNerfBiasBytes / (C::NWAVES * 1024); ++j)
             lds_dma16(a.bias + (j * C::NWAVES + wave) * 1024 + lane * 16, smem + C::RING_BYTES + (j * C::NWAVES + wave) * 1024);
-        // chunks 0..6 of the stream: the state every pass's entry expects (the first entry's counted wait also covers the
-        // bias table: it is older than the chunks)
-        ring.next = ring.src[0];
-        ring.persist_prologue();
+        // chunks 0 .. kLook-1 of the stream: the state every pass's entry expects (the first entry's counted wait also covers
+        // the bias table: it is older than the chunks)
+        ring.lds_wave = smem + wave * kPiece;
+        ring.voff = wave * kPiece + lane * 16;
+        static_for<kLook * (kPiece / 1024)>([&](auto i_) {
+            constexpr int i = decltype(i_)::value, ch = i / (kPiece / 1024), j = i % (kPiece / 1024);
+            lds_dma16_s<(j % 4) * 1024>(ring.src[0] + ch * kChunk + (j / 4) * 4096, ring.voff, ring.lds_wave + ch * kChunk + (j / 4) * 4096);
+        });
     }
 
     for (long long p = blockIdx.x; p < n_pass; p += gridDim.x) {
@@ -57,7 +63,7 @@ __global__ void __launch_bounds__(256, 1) nerf_x3s_kernel(NerfArgs a, long long 
         }
         // per-lane addresses from a lane id read HERE: nothing but them and the loop's scalars lives across the stream
         const int fl = fresh_lane_id();
-        ring.voff = wave * (C::GPC * 1024) + fl * 16;
+        ring.voff = wave * kPiece + fl * 16;
         ring.lane_lo = opaque((lds_cptr)smem + fl * 16);
         ring.lane_hi = opaque((lds_cptr)smem + 65536 + fl * 16);
         const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * (fl >> 4));

@@ -129,7 +129,12 @@ class Pass2:
         e.emit("s_add_u32 m0, %%[ldsw], 0x%x" % (slot * CHUNK))
         e.emit("s_nop 0")
         for j in range(GPC):
-            line = "global_load_lds_dwordx4 %%[voff], s[96:97] offset:%d" % (j * 1024)
+            if j == 4:                       # the instruction's offset field ends at 4095: second half of a 32 KiB chunk's piece
+                self.dma_q.append("s_add_u32 s96, s96, 0x1000")
+                self.dma_q.append("s_addc_u32 s97, s97, 0")
+                self.dma_q.append("s_add_u32 m0, m0, 0x1000")
+                self.dma_q.append("s_nop 0")
+            line = "global_load_lds_dwordx4 %%[voff], s[96:97] offset:%d" % ((j % 4) * 1024)
             if self.cfg.get("spread_dma", 1):
                 self.dma_q.append(line)      # issued one per MFMA gap (drain_dma): four in a row hold the wave's issue for ~4 x 16 clocks
             else:
@@ -137,9 +142,10 @@ class Pass2:
         self.entered = v
 
     def drain_dma(self, n=1):
-        while self.dma_q and n > 0:
-            self.e.emit(self.dma_q.pop(0))
-            n -= 1
+        while self.dma_q and n > 0:          # (the scalar set-up lines in front of a load go with it)
+            line = self.dma_q.pop(0)
+            self.e.emit(line)
+            n -= line.startswith("global_load")
 
     def acquire_for(self, q):
         g = min(q, self.nq - 1)
@@ -441,7 +447,7 @@ def block_text(lines):
 
 
 def emit_pass(name, table, layers, nq, units, out, cfg=None):
-    nchunk = (units + 15) // 16
+    nchunk = (units * 1024 + CHUNK - 1) // CHUNK
     padc = (nchunk + SLOTS - 1) // SLOTS * SLOTS
     gen = Pass2(table, layers, nq, padc, cfg)
     lines = gen.generate()
@@ -454,7 +460,7 @@ def emit_pass(name, table, layers, nq, units, out, cfg=None):
     out.append("// keep[ct][0..5] = Ph[0], Ph[1], Pl[0], Pl[1], Dh, Dl of column tile ct (fp16 hi / lo B fragments of the encodings), handed over in")
     out.append("// v122..v169 and moved to a152..a199 by the stream; sigma[ct] (lanes 0..15) and rows 0..2 of the colour head's accumulator come")
     out.append("// back in v16..v23.  The stream runs the whole ring protocol of one pass (entry, boundaries, walk to the padded end).")
-    out.append("constexpr int kMx2PadChunks = %d;" % padc)
+    out.append("constexpr int kMx2PadChunks = %d, kMx2ChunkBytes = %d;" % (padc, CHUNK))
     out.append("template <class Reader>")
     out.append("__device__ __forceinline__ void mx2_asm_%s(const Reader& rd, lds_cptr bias_lane, lds_cptr rs_lane, half8 (&keep)[2][6], float (&sigma)[2], float (&rgb)[2][3]) {" % name)
     out.append("    const unsigned src_lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)rd.ring.src[0]), src_hi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)rd.ring.src[0] >> 32));")
@@ -481,11 +487,22 @@ def emit_pass(name, table, layers, nq, units, out, cfg=None):
     out.append("")
 
 
+def set_chunk(chunk):
+    """ring of 128 KiB in chunks of `chunk` bytes (16 KiB: 8 slots, 32 KiB: 4 slots, half the boundaries)"""
+    global CHUNK, SLOTS, LOOK, GPC
+    import gen_mx_asm as G
+    G.CHUNK = CHUNK = chunk
+    G.SLOTS = SLOTS = RING // chunk
+    G.LOOK = LOOK = SLOTS - 1
+    GPC = CHUNK // (NWAVES * 1024)
+
+
 def main():
     cfg = {}
     for a in sys.argv[1:]:
         k, v = a.split("=")
         cfg[k] = int(v)
+    set_chunk(cfg.get("chunk", CHUNK))
     out = ["// GENERATED by tools/gen_mx2_asm.py %s-- do not edit; see that file for the design." % ("".join(x + " " for x in sys.argv[1:])), ""]
     t = Table(NERF_SHAPES)
     nq = t.first[12]

@@ -106,9 +106,10 @@ class PassX3:
 
     # ------------------------------------------------------------------------------------------ ring
     def drain_dma(self, n=1):
-        while self.dma_q and n > 0:
-            self.e.emit(self.dma_q.pop(0))
-            n -= 1
+        while self.dma_q and n > 0:          # (the scalar set-up lines in front of a load go with it)
+            line = self.dma_q.pop(0)
+            self.e.emit(line)
+            n -= line.startswith("global_load")
 
     def boundary(self, v):
         e = self.e
@@ -128,7 +129,9 @@ class PassX3:
         e.emit("s_add_u32 m0, %%[ldsw], 0x%x" % (slot * CHUNK))
         e.emit("s_nop 0")
         for j in range(GPC):
-            self.dma_q.append("global_load_lds_dwordx4 %%[voff], s[96:97] offset:%d" % (j * 1024))
+            if j == 4:                       # the instruction's offset field ends at 4095: second half of a 32 KiB chunk's piece
+                self.dma_q.extend(["s_add_u32 s96, s96, 0x1000", "s_addc_u32 s97, s97, 0", "s_add_u32 m0, m0, 0x1000", "s_nop 0"])
+            self.dma_q.append("global_load_lds_dwordx4 %%[voff], s[96:97] offset:%d" % ((j % 4) * 1024))
         self.entered = v
 
     def acquire_for(self, f):
@@ -343,7 +346,7 @@ def emit_pass(name, layers, out, cfg=None):
     out.append("// keep[ct][0..3] = Ph[0], Ph[1], Pl[0], Pl[1] of column tile ct (fp16 hi / lo B fragments of the point encoding), handed over in")
     out.append("// v60..v91 and moved to a192..a223 by the stream; sigma[ct] (lanes 0..15) comes back in v16, v17.  The stream runs the whole ring")
     out.append("// protocol of one pass (entry, boundaries, walk to the padded end).")
-    out.append("constexpr int kX3sFrags = %d, kX3sPadChunks = %d;" % (gen.nfrag, gen.padc))
+    out.append("constexpr int kX3sFrags = %d, kX3sPadChunks = %d, kX3sChunkBytes = %d;" % (gen.nfrag, gen.padc, CHUNK))
     out.append("template <class Ring>")
     out.append("__device__ __forceinline__ void x3_asm_%s(const Ring& ring, lds_cptr bias_lane, half8 (&keep)[2][4], float (&sigma)[2]) {" % name)
     out.append("    const unsigned src_lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ring.src[0]), src_hi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)ring.src[0] >> 32));")
@@ -368,11 +371,22 @@ def emit_pass(name, layers, out, cfg=None):
     out.append("")
 
 
+def set_chunk(chunk):
+    """ring of 128 KiB in chunks of `chunk` bytes (16 KiB: 8 slots, 32 KiB: 4 slots, half the boundaries)"""
+    global CHUNK, SLOTS, LOOK, GPC, FPC
+    CHUNK = chunk
+    SLOTS = 131072 // chunk
+    LOOK = SLOTS - 1
+    GPC = CHUNK // (NWAVES * 1024)
+    FPC = CHUNK // FRAG
+
+
 def main():
     cfg = {}
     for a in sys.argv[1:]:
         k, v = a.split("=")
         cfg[k] = int(v)
+    set_chunk(cfg.get("chunk", CHUNK))
     out = ["// GENERATED by tools/gen_x3_asm.py %s-- do not edit; see that file for the design." % ("".join(x + " " for x in sys.argv[1:])), ""]
     emit_pass("nerf_sigma_pass", nerf_sigma_layers(), out, cfg)
     print("\n".join(out))

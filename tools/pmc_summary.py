@@ -32,7 +32,7 @@ for sub in ("fetch", "write", "sq", "sq2"):
         acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("== counters:", sub)
     for k, cs in sorted(acc.items(), key=lambda kv: -max(sum(v) for v in kv[1].values())):
-        if not any(x in k for x in ("fused_render", "styled", "nerf_mlp", "nerf_mx", "gemm_kernel", "attn")):
+        if not any(x in k for x in ("fused_render", "styled", "nerf_mlp", "nerf_mx", "nerf_x3s", "gemm_kernel", "attn")):
             continue
         print(" ", k)
         for c, v in sorted(cs.items()):

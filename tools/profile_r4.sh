@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round-4 profiles: every precision of the HEADLINE ALONE (one kernel, one workload per run -- round 2's profile mixed the
+# Round-4 profiles: every precision of the HEADLINE ALONE (one workload per run; fp16x3+fp16mx twice: the split path the library
+# picks, and -- TGTC_BENCH_SINGLE=1 -- the single ray kernel -- round 2's profile mixed the
 # headline's 400x400 frames with the trex frames of `--configs`), then the stylised config by itself.
 #   per run:  1. rocprofv3 --kernel-trace --stats      2./3. --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)
 #             4./5. --pmc SQ_* GRBM_GUI_ACTIVE: wait classes, then instruction mix + LDS (VERDICT r3 item 1's list; counter passes
@@ -25,6 +26,7 @@ run() {   # run <tag> <bench args...>
 }
 COMMON="--steps 4 --warmup 2 --cpu-rays 0 --alt-precision="
 run headline_x3mx $COMMON --configs= --precision fp16x3+fp16mx && \
+TGTC_BENCH_SINGLE=1 run headline_x3mx_single $COMMON --configs= --precision fp16x3+fp16mx && \
 run headline_x3   $COMMON --configs= --precision fp16x3 && \
 run styled        $COMMON --configs=styled --precision fp16x3+fp16mx
-for d in headline_x3mx headline_x3 styled; do echo "==== $d"; cat $TOP/$d/summary.txt; done
+for d in headline_x3mx headline_x3mx_single headline_x3 styled; do echo "==== $d"; cat $TOP/$d/summary.txt; done

@@ -31,7 +31,9 @@ d = {"collected": "tools/profile_%s.sh on MI355X" % tag + ": rocprofv3 --pmc FET
              "an XCD's 4 MiB L2 at each coarse<->fine phase change; rays in and pixels out are 10.2 MB.",
      "kernels": {}}
 for name, run, key, what in (
-        ("fused_render_kernel:fp16x3+fp16mx", "headline_x3mx", "fused_render_kernel<0, 2>", "fused_render_kernel<0,2>, 160000 rays of a 400x400 frame per dispatch (headline alone)"),
+        ("nerf_mx2_kernel", "headline_x3mx", "nerf_mx2_kernel", "nerf_mx2_kernel<IN_RAYS>, the fine pass of 160000 rays x 192 depths per dispatch (headline alone, split path)"),
+        ("nerf_x3s_kernel", "headline_x3mx", "nerf_x3s_kernel", "nerf_x3s_kernel, the coarse pass of 160000 rays x 128 depths per dispatch (headline alone, split path)"),
+        ("fused_render_kernel:fp16x3+fp16mx", "headline_x3mx_single", "fused_render_kernel<0, 2>", "fused_render_kernel<0,2>, 160000 rays of a 400x400 frame per dispatch (TGTC_BENCH_SINGLE=1)"),
         ("fused_render_kernel:fp16x3", "headline_x3", "fused_render_kernel<0, 0>", "fused_render_kernel<0,0>, 160000 rays of a 400x400 frame per dispatch (headline alone)"),
         ("styled:fp16x3+fp16mx", "styled", "styled", "stylised render kernel(s), 160000 rays of a 400x400 frame per dispatch (--configs styled)")):
     f, n = mean(run, 'fetch', 'FETCH_SIZE', key)
@@ -43,7 +45,7 @@ for name, run, key, what in (
                           "source": "%s, n=%d dispatches" % (what, n)}
     print(name, round(2 * f * 1024 / 1e9, 3), 'GB fetched (corrected)', round(w * 1024 / 1e9, 4), 'GB written', n)
 json.dump(d, open('profiles/pmc_traffic.json', 'w'), indent=1)
-for run in ("headline_x3mx", "headline_x3", "styled"):
+for run in ("headline_x3mx", "headline_x3mx_single", "headline_x3", "styled"):
     if os.path.exists('%s/%s/summary.txt' % (top, run)):
         shutil.copy('%s/%s/summary.txt' % (top, run), 'profiles/%s_%s_rocprof_summary.txt' % (tag, run))
         shutil.copy('%s/%s/bench_stats.json' % (top, run), 'profiles/%s_%s_bench_under_rocprof.json' % (tag, run))
