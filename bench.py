@@ -95,27 +95,52 @@ def mfma_per_product(precision):
     return (MFMA_PER_PRODUCT[pc] * fc + MFMA_PER_PRODUCT[pf] * ff) / (fc + ff)
 
 
-def cpu_baseline(n_rays, chunk=1024):
+def cpu_budget():
+    """CPUs this job may actually use: its affinity mask, capped by the cgroup's CPU quota where one is set -- a GPU box hands a
+    one-GPU job 16 CPUs' worth of a 256-CPU host through the quota, not through the mask (256 threads on that share ran the
+    baseline 15x slower than 16).  Returns (threads, how they were chosen)."""
+    n = len(os.sched_getaffinity(0))
+    how = "the job's affinity mask (%d CPUs)" % n
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            quota, period = parse(open(path).read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(round(int(quota) / int(period))))
+                if q < n:
+                    n, how = q, "the cgroup CPU quota (%s / %s) inside an affinity mask of %d" % (quota, period, len(os.sched_getaffinity(0)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if n > 32:      # no quota visible on a many-core host: the pool's documented share for a one-GPU job
+        n, how = 16, "16: the GPU pool's CPU share of a one-GPU job (no cgroup quota visible; affinity mask %d CPUs)" % len(os.sched_getaffinity(0))
+    return n, how
+
+
+def cpu_baseline(n_rays, chunk=1024, budget_s=25.0):
     """The CPU oracle (plain PyTorch restatement of the reference, pinned to the reference's goldens) on a
-    bounded sample of the same workload; same chunking as the reference CLI (--chunk 1024)."""
+    bounded sample of the same workload; same chunking as the reference CLI (--chunk 1024).  Stops after `budget_s` seconds
+    of timed work if the sample has not been rendered by then (the rate is per ray either way)."""
     from oracle import fields, rays
     from tgtc_style_amd import synth
-    # every core this job may run on (BASELINE.md section 3: "all physical cores, stated"); the box's total is reported next to it
-    cores = len(os.sched_getaffinity(0))
+    cores, how = cpu_budget()
     torch.set_num_threads(cores)
     c, f = t_state(synth.nerf_state(0)), t_state(synth.nerf_state(1))
     o, d = rays.frame_rays_ndc(H, W, synth.fern_intrinsics(H, W), synth.spiral_pose(0))
     o, d = torch.from_numpy(o[:n_rays + chunk]), torch.from_numpy(d[:n_rays + chunk])
+    done = 0
     with torch.no_grad():
         fields.render_plain(c, f, o[:chunk], d[:chunk], N_COARSE, N_FINE)       # warm-up chunk
         t0 = time.perf_counter()
         for lo in range(chunk, chunk + n_rays, chunk):
             fields.render_plain(c, f, o[lo:lo + chunk], d[lo:lo + chunk], N_COARSE, N_FINE)
+            done += min(chunk, chunk + n_rays - lo)
+            if time.perf_counter() - t0 > budget_s:
+                break
         dt = time.perf_counter() - t0
-    return {"value": n_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port", "host_cpus": os.cpu_count(),
-            "sample": "%d rays of the same 400x400 frame in chunks of %d after one warm-up chunk, "
-                      "torch %s CPU fp32, %d threads = every CPU of this job's affinity mask (the host has %s), %.1f s" % (
-                          n_rays, chunk, torch.__version__, cores, os.cpu_count(), dt)}
+    return {"value": done / dt, "unit": "rays/s", "cores": cores, "kind": "port", "host_cpus": os.cpu_count(),
+            "sample": "%d rays of the same 400x400 frame in chunks of %d after one warm-up chunk, torch %s CPU fp32, "
+                      "%d threads = %s (the host has %s CPUs), %.1f s" % (done, chunk, torch.__version__, cores, how, os.cpu_count(), dt)}
 
 
 def pmc_traffic(kernel):

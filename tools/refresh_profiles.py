@@ -41,9 +41,12 @@ for name, run, key, what in (
     if f is None or w is None:
         print("no counters for", name)
         continue
-    d['kernels'][name] = {"fetch_bytes_raw": f * 1024, "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024,
+    # the per-sample kernels fetch their depths with 4-byte-per-lane loads (FETCH_SIZE exact: calibrated in round 1 on this very
+    # access, DESIGN.md section 3.1 Roofline) and 2 MB of weights per XCD; the x2 of the guide applies to 16-byte-per-lane streams
+    k = 1.0 if name.startswith("nerf_") else 2.0
+    d['kernels'][name] = {"fetch_bytes_raw": f * 1024, "fetch_bytes": k * f * 1024, "fetch_correction": k, "write_bytes": w * 1024,
                           "source": "%s, n=%d dispatches" % (what, n)}
-    print(name, round(2 * f * 1024 / 1e9, 3), 'GB fetched (corrected)', round(w * 1024 / 1e9, 4), 'GB written', n)
+    print(name, round(k * f * 1024 / 1e9, 3), 'GB fetched (corrected x%g)' % k, round(w * 1024 / 1e9, 4), 'GB written', n)
 json.dump(d, open('profiles/pmc_traffic.json', 'w'), indent=1)
 for run in ("headline_x3mx", "headline_x3mx_single", "headline_x3", "styled"):
     if os.path.exists('%s/%s/summary.txt' % (top, run)):
