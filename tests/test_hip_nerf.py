@@ -172,6 +172,20 @@ def test_two_tile_fp16mx_kernel_matches_the_one_tile_kernel_bit_for_bit(M):
     assert torch.equal(out["two_tile"][0], out["one_tile"][0]) and torch.equal(out["two_tile"][1], out["one_tile"][1])
     ref = fields.style_nerf(T(synth.nerf_state(1)), pts.cpu(), dirs.cpu())
     assert rel(out["two_tile"][0].cpu(), ref["rgb"]) <= 1e-3 and rel(out["two_tile"][1].cpu(), ref["sigma"]) <= 1e-3
+    # already-encoded inputs (MLP_style.forward's boundary): the same two kernels behind tgtc_nerf_mlp_forward
+    pe, de = fields.posenc(pts.cpu(), 10).float().cuda().contiguous(), fields.posenc(dirs.cpu(), 4).float().cuda().contiguous()
+    enc = {}
+    for tag in ("two_tile", "one_tile"):
+        rgb, sigma = torch.full((M, 3), -7.0, device="cuda"), torch.full((M,), -7.0, device="cuda")
+        remap = torch.empty(M, 256, device="cuda") if tag == "one_tile" else None
+        hip.check(lib.tgtc_nerf_mlp_forward(h, hip.ptr(pe), hip.ptr(de), M, hip.ptr(rgb), hip.ptr(sigma), hip.ptr(remap), hip.stream()))
+        enc[tag] = (rgb, sigma)
+    assert torch.equal(enc["two_tile"][0], enc["one_tile"][0]) and torch.equal(enc["two_tile"][1], enc["one_tile"][1])
+    # the encodings as outputs (tgtc_nerf_forward's pts / dirs), written by the two-tile kernel's front end
+    pe_o, de_o = torch.empty(M, 63, device="cuda"), torch.empty(M, 27, device="cuda")
+    rgb, sigma = torch.empty(M, 3, device="cuda"), torch.empty(M, device="cuda")
+    hip.check(lib.tgtc_nerf_forward(h, hip.ptr(pts), hip.ptr(dirs), M, hip.ptr(rgb), hip.ptr(sigma), None, hip.ptr(pe_o), hip.ptr(de_o), hip.stream()))
+    assert torch.equal(rgb, out["two_tile"][0]) and float((pe_o.cpu() - pe.cpu()).abs().max()) <= 5e-5 and float((de_o.cpu() - de.cpu()).abs().max()) <= 5e-5
     # rays as input (the render chain's fine pass)
     R, N = max(M // 192, 1), 192
     ro = torch.from_numpy(rng.uniform(-0.3, 0.3, (R, 3))).cuda()
