@@ -42,9 +42,11 @@ typedef _Float16 half32 __attribute__((ext_vector_type(32)));
 // ------------------------------------------------------------------------------------------------ stream layout
 // The stream is a sequence of GROUPS, one LDS->register burst each:
 //   K group (one 128-deep block of one row tile), 7 KiB:  [Wh k-step 0..3: 4 x 1 KiB][Wl6 dwords 0-3: 1 KiB]
-//                                                         [Wh6 dwords 0-3: 1 KiB], lane*16; [Wl6 dwords 4-5: 512 B]
-//                                                         [Wh6 dwords 4-5: 512 B], lane*8 -- so that each fp6 operand
-//                                                         lands in six consecutive registers without copies
+//                                                         [Wl6 dwords 4-5 | Wh6 dwords 0-1: 1 KiB][Wh6 dwords 2-5: 1 KiB],
+//                                                         all lane*16: seven ds_read_b128 per group, and the two fp6
+//                                                         operands land in twelve consecutive registers without copies
+//                                                         (rounds 1-3: 2 x b128 + 2 x b64; the generated streams issue one
+//                                                         instruction less per group -- what a lone wave pays for is issue)
 //   P group (the PE / direction k-steps of one row tile), npe x 2 KiB: [hi, lo] per k-step, lane*16
 // Groups never straddle the end of the 128 KiB ring (padding inserted), they may straddle 16 KiB chunks.
 struct MxShape {
@@ -153,15 +155,19 @@ struct MxReader {
             if constexpr (J < units(Q)) {
                 if constexpr (J < 4) {
                     ub[Q % DEPTH][J] = read16<T.off[Q] + 1024 * J>();
-                } else if constexpr (J < 6) {
-                    const u4v t = __builtin_bit_cast(u4v, read16<T.off[Q] + 1024 * J>());
-                    u6v& w = wb[Q % DEPTH][J - 4];
+                } else if constexpr (J == 4) {          // piece A: Wl6 dwords 0-3 (its registers are free once C1 has issued)
+                    const u4v t = __builtin_bit_cast(u4v, read16<T.off[Q] + 4096>());
+                    u6v& w = wb[Q % DEPTH][0];
                     w[0] = t[0], w[1] = t[1], w[2] = t[2], w[3] = t[3];
-                } else {
-                    const u2v t = read8<T.off[Q] + 6144 + 512 * (J - 6)>();
-                    u6v& w = wb[Q % DEPTH][J - 6];
-                    w[4] = t[0], w[5] = t[1];
-                }
+                } else if constexpr (J == 5) {          // piece C: Wh6 dwords 2-5 (free once C2 has issued)
+                    const u4v t = __builtin_bit_cast(u4v, read16<T.off[Q] + 6144>());
+                    u6v& w = wb[Q % DEPTH][1];
+                    w[2] = t[0], w[3] = t[1], w[4] = t[2], w[5] = t[3];
+                } else if constexpr (J == 7) {          // piece B: Wl6 dwords 4-5 | Wh6 dwords 0-1 -- needs BOTH operands released,
+                    const u4v t = __builtin_bit_cast(u4v, read16<T.off[Q] + 5120>());   // so it rides with unit 5, behind C2
+                    wb[Q % DEPTH][0][4] = t[0], wb[Q % DEPTH][0][5] = t[1];
+                    wb[Q % DEPTH][1][0] = t[2], wb[Q % DEPTH][1][1] = t[3];
+                }                                       // (J == 6: nothing -- seven LDS reads per K group, round 4)
             }
         }
     }

@@ -179,10 +179,11 @@ int nerf_mx_pack(const tgtc_linear* layers, std::vector<char>& bias_region, std:
                             put(bl, 8 * s + j, e2m3_encode((w - (float)hi) * inv_l));
                             put(bh, 8 * s + j, e2m3_encode((float)hi * inv_h));
                         }
+                    // three 16-byte pieces per lane (mlp_mx.h): [Wl6 dwords 0-3] [Wl6 4-5 | Wh6 0-1] [Wh6 2-5]
                     std::memcpy(base + 4096 + lane * 16, &bl[0], 16);
-                    std::memcpy(base + 5120 + lane * 16, &bh[0], 16);
-                    std::memcpy(base + 6144 + lane * 8, &bl[2], 8);
-                    std::memcpy(base + 6656 + lane * 8, &bh[2], 8);
+                    std::memcpy(base + 5120 + lane * 16, &bl[2], 8);
+                    std::memcpy(base + 5120 + lane * 16 + 8, &bh[0], 8);
+                    std::memcpy(base + 6144 + lane * 16, &bh[1], 16);
                 }
             }
             if (sh.npe) {

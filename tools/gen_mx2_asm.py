@@ -162,7 +162,7 @@ class Pass2:
         if n:
             return [(j, 4 * j, 4, 1024 * j, True) for j in range(2 * n)]
         return [(0, 0, 4, 0, True), (1, 4, 4, 1024, True), (2, 8, 4, 2048, True), (3, 12, 4, 3072, True),
-                (4, 16, 4, 4096, True), (6, 20, 2, 6144, False), (5, 22, 4, 5120, True), (7, 26, 2, 6656, False)]
+                (4, 16, 4, 4096, True), (6, 20, 4, 5120, True), (5, 24, 4, 6144, True)]      # fp6 pieces A, B, C (mlp_mx.h)
 
     def read_unit_at(self, q, unit):
         u, roff, nreg, boff, wide = unit

@@ -389,7 +389,7 @@ class PassGen(BlockGen):
         if n:
             return [(j, 4 * j, 4, 1024 * j, True) for j in range(2 * n)]
         return [(0, 0, 4, 0, True), (1, 4, 4, 1024, True), (2, 8, 4, 2048, True), (3, 12, 4, 3072, True),
-                (4, 16, 4, 4096, True), (6, 20, 2, 6144, False), (5, 22, 4, 5120, True), (7, 26, 2, 6656, False)]
+                (4, 16, 4, 4096, True), (6, 20, 4, 5120, True), (5, 24, 4, 6144, True)]      # fp6 pieces A, B, C (mlp_mx.h)
 
     def read_unit_at(self, q, unit):
         u, roff, nreg, boff, wide = unit
@@ -698,7 +698,7 @@ def emit_block(name, table, q0, nlayers, bias0, nq_pass, units_pass, cfg, out):
 def main():
     global CHUNK, SLOTS, GPC, LOOK
     which = sys.argv[1] if len(sys.argv) > 1 else "bench"
-    cfg = {"dist": 2, "max_fill": 3}
+    cfg = {"dist": 2, "max_fill": 3, "b128": 1}      # b128: the stream layout since round 4 (seven reads per K group)
     for a in sys.argv[2:]:
         k, v = a.split("=")
         cfg[k] = int(v)
