@@ -67,6 +67,60 @@ __global__ void __launch_bounds__(256, 1) k(long long* clk, float* out, int iter
     if ((threadIdx.x & 63) == 0) clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// The same question for 32x32x16 MFMAs (8 passes, twice the flops per instruction): two alternating chains (accumulators
+// v[100:115], v[116:131]), A in a[10:13], B in v[120:123] / v[124:127]; VAR bit 0: + two VALU per MFMA, bit 1: + one ds_read_b128
+// (into AGPRs) per MFMA -- the per-flop instruction mix of k<27> above.
+template <int VAR>
+__global__ void __launch_bounds__(256, 1) k32(long long* clk, float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + threadIdx.x * 16;
+    asm volatile("v_mov_b32 v100, 0\n\tv_mov_b32 v101, 0\n\tv_mov_b32 v102, 0\n\tv_mov_b32 v103, 0\n\tv_mov_b32 v104, 0\n\tv_mov_b32 v105, 0\n\t"
+                 "v_mov_b32 v106, 0\n\tv_mov_b32 v107, 0\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v109, 0\n\tv_mov_b32 v110, 0\n\tv_mov_b32 v111, 0\n\t"
+                 "v_mov_b32 v112, 0\n\tv_mov_b32 v113, 0\n\tv_mov_b32 v114, 0\n\tv_mov_b32 v115, 0\n\tv_mov_b32 v116, 0\n\tv_mov_b32 v117, 0\n\t"
+                 "v_mov_b32 v118, 0\n\tv_mov_b32 v119, 0\n\tv_mov_b32 v132, 0\n\tv_mov_b32 v133, 0\n\tv_mov_b32 v134, 0\n\tv_mov_b32 v135, 0\n\t"
+                 "v_mov_b32 v136, 0\n\tv_mov_b32 v137, 0\n\tv_mov_b32 v138, 0\n\tv_mov_b32 v139, 0\n\tv_mov_b32 v140, 0\n\tv_mov_b32 v141, 0\n\t"
+                 "v_mov_b32 v142, 0\n\tv_mov_b32 v143, 0\n\t" ::: "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v170", "v171", "v172", "v173", "a60", "a61", "a62", "a63");
+    const long long t0 = __builtin_amdgcn_s_memtime();
+#define BIG(acc, B) "v_mfma_f32_32x32x16_f16 " acc ", a[10:13], " B ", " acc "\n\t"
+#define VV2(a, b) "v_max_i32_e32 v17" #a ", 0, v17" #a "\n\tv_max_i32_e32 v17" #b ", 0, v17" #b "\n\t"
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (VAR == 0)
+            asm volatile(BIG("v[100:115]", "v[120:123]") BIG("v[132:147]", "v[124:127]") BIG("v[100:115]", "v[120:123]") BIG("v[132:147]", "v[124:127]")
+                         BIG("v[100:115]", "v[120:123]") BIG("v[132:147]", "v[124:127]") ::"v"(lds) : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v170", "v171", "v172", "v173", "a60", "a61", "a62", "a63");
+        else if constexpr (VAR == 1)
+            asm volatile(BIG("v[100:115]", "v[120:123]") VV2(0, 1) BIG("v[132:147]", "v[124:127]") VV2(2, 3) BIG("v[100:115]", "v[120:123]") VV2(0, 1)
+                         BIG("v[132:147]", "v[124:127]") VV2(2, 3) BIG("v[100:115]", "v[120:123]") VV2(0, 1) BIG("v[132:147]", "v[124:127]") VV2(2, 3) ::"v"(lds) : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v170", "v171", "v172", "v173", "a60", "a61", "a62", "a63");
+        else
+            asm volatile(BIG("v[100:115]", "v[120:123]") VV2(0, 1) LDA(0) BIG("v[132:147]", "v[124:127]") VV2(2, 3) LDA(4096) BIG("v[100:115]", "v[120:123]") VV2(0, 1) LDA(8192)
+                         BIG("v[132:147]", "v[124:127]") VV2(2, 3) LDA(12288) BIG("v[100:115]", "v[120:123]") VV2(0, 1) LDA(16384) BIG("v[132:147]", "v[124:127]") VV2(2, 3) LDA(20480)
+                         ::"v"(lds) : "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v170", "v171", "v172", "v173", "a60", "a61", "a62", "a63");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float r;
+    asm volatile("v_mov_b32 %0, v100" : "=v"(r));
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int VAR>
+static void run32(const char* name, long long* dclk, float* dout, int iters) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k32<VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+    hipLaunchKernelGGL((k32<VAR>), dim3(256), dim3(256), 98304, 0, dclk, dout, 64);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k32<VAR>), dim3(256), dim3(256), 98304, 0, dclk, dout, iters);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double slots = 4.0 * iters * 6 * 2.0;      // six 32x32x16 per iteration and wave = twelve 16x16x32-equivalents
+    printf("%-44s %8.3f ms  matrix pipe %.3f\n", name, ms, slots * 16384.0 / (ms * 1e-3) / (2.5e15 / 256));
+}
+
 template <int VAR>
 static void run(const char* name, long long* dclk, float* dout, int iters) {
     hipEvent_t e0, e1;
@@ -108,6 +162,9 @@ int main(int argc, char** argv) {
         run<24>("all VGPR + VALU + ds_read_b128 / 2 MFMA", dclk, dout, iters);
         run<27>("plan + VALU + ds_read_b128 (to AGPR) / 2 MFMA", dclk, dout, iters);
         run<59>("plan + VALU + reads + cvt_scalef32 / 48 MFMA", dclk, dout, iters);
+        run32<0>("32x32x16: two chains, A in AGPRs", dclk, dout, iters);
+        run32<1>("32x32x16 + 2 VALU / MFMA", dclk, dout, iters);
+        run32<2>("32x32x16 + 2 VALU + ds_read_b128 / MFMA", dclk, dout, iters);
     }
     return 0;
 }
