@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-4 profiles: every precision of the HEADLINE ALONE (one workload per run; fp16x3+fp16mx twice: the split path the library
-# picks, and -- TGTC_BENCH_SINGLE=1 -- the single ray kernel -- round 2's profile mixed the
-# headline's 400x400 frames with the trex frames of `--configs`), then the stylised config by itself.
+# Round-4 profiles: every precision of the HEADLINE ALONE, one workload per run (round 2 mixed the headline with the configs);
+# fp16x3+fp16mx twice -- the split path the library picks and, TGTC_BENCH_SINGLE=1, the single ray kernel --
+# then strict fp16x3 and the stylised config by itself.
 #   per run:  1. rocprofv3 --kernel-trace --stats      2./3. --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)
 #             4./5. --pmc SQ_* GRBM_GUI_ACTIVE: wait classes, then instruction mix + LDS (VERDICT r3 item 1's list; counter passes
 #                   carry no trace domain; the program follows `--` directly)
