@@ -38,6 +38,10 @@ bad = 0
 for prec in ("fp16x3+fp16mx", "fp16x3", "fp16"):
     r = bench.make_renderer(prec, False)
     bad += soak("plain " + prec, lambda i: (lambda o: (o["rgb"], o["t"]))(r.render(*rays[i], 128, 64, near=0., far=1.)), 3)
+    if r._split_is_faster():    # the library's choice above was the split path (two-tile kernels); the single ray kernel as well
+        from tgtc_style_amd import rendering
+        r1 = rendering.RayRenderer(r.coarse, r.fine, fused="single")
+        bad += soak("plain " + prec + " (single kernel)", lambda i: (lambda o: (o["rgb"], o["t"]))(r1.render(*rays[i], 128, 64, near=0., far=1.)), 3)
 r = bench.make_renderer("fp16x3", True)
 z = torch.from_numpy(np.random.default_rng(4).standard_normal((H * W, 32)).astype(np.float32)).cuda()
 bad += soak("styled fp16x3", lambda i: (lambda o: (o["rgb"], o["t"]))(r.render(*rays[i], 128, 64, near=0., far=1., z=z)), 3)
