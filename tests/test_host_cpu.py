@@ -91,3 +91,19 @@ def test_all_five_scene_configs_parse_and_name_their_outputs():
         seen[scene] = (a.loss_coh_lambda, a.valid_factor, a.total_step)
     assert seen == {"fern": (1e2, 3, 128001), "flower": (1e2, 3, 128000), "horns": (1e2, 2, 128001),
                     "orchids": (5e2, 3, 128001), "trex": (1e2, 2, 128001)}
+
+
+@pytest.mark.parametrize("tool,args,inc", [("gen_mx_asm.py", ["nerf"], "mx_asm_nerf.inc"), ("gen_mx2_asm.py", [], "mx2_asm_nerf.inc"),
+                                            ("gen_x3_asm.py", [], "x3_asm_nerf.inc")])
+def test_generated_instruction_streams_are_current(tool, args, inc):
+    """The committed csrc/*.inc files are exactly what tools/gen_*_asm.py emits today (the kernels' static_asserts pin the ring
+    layout they were generated for; this pins the text: a generator edit without a regenerate, or the reverse, fails here)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", tool)] + args, capture_output=True, text=True, check=True).stdout
+    with open(os.path.join(root, "tgtc-style_amd", "csrc", inc)) as f:
+        committed = f.read()
+    assert out == committed, "%s is stale: python tools/%s %s > tgtc-style_amd/csrc/%s" % (inc, tool, " ".join(args), inc)
+    # every MFMA of a stream names an accumulator the stream owns, and the stream ends with the LDS queue drained
+    assert out.count("v_mfma_") > 1000 and "s_waitcnt lgkmcnt(0)" in out
