@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256, 1) nerf_mx2_kernel(NerfArgs a, long long 
         const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * (fl >> 4));
         const lds_cptr rs_lane = opaque((lds_cptr)smem + C::RING_BYTES + kNerfMxScaleOff + 2 * (fl & 15));
         float sigma[2], rgb[2][3];
-        mx2_asm_nerf_full_pass(rd, bias_lane, rs_lane, keep, sigma, rgb);
+        mx2_asm_nerf_full_pass(rd, wave, bias_lane, rs_lane, keep, sigma, rgb);
         const int lane = fresh_lane_id();
         if (lane < 16 && !(TGTC_MX2_ABL & 2)) {   // (2: timing experiment without the output stores)
 #pragma unroll

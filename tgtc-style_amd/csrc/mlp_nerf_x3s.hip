@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256, 1) nerf_x3s_kernel(NerfArgs a, long long 
         ring.lane_hi = opaque((lds_cptr)smem + 65536 + fl * 16);
         const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * (fl >> 4));
         float sigma[2];
-        x3_asm_nerf_sigma_pass(ring, bias_lane, keep, sigma);
+        x3_asm_nerf_sigma_pass(ring, wave, bias_lane, keep, sigma);
         const int lane = fresh_lane_id();
         if (lane < 16) {
 #pragma unroll

@@ -102,6 +102,7 @@ class Pass2:
         self.e = Emitter()
         self.unit_op, self.unit_chunk = {}, {}
         self.dma_q = []
+        self.dma_n = self.dma_tick = 0
         self.entered = -1
         self.exit_entered = max(table.chunk_hi(nq - 1) - 1, 0)
 
@@ -128,24 +129,41 @@ class Pass2:
         e.emit("s_addc_u32 s97, %[src_hi], 0")
         e.emit("s_add_u32 m0, %%[ldsw], 0x%x" % (slot * CHUNK))
         e.emit("s_nop 0")
+        loads = []
         for j in range(GPC):
             if j == 4:                       # the instruction's offset field ends at 4095: second half of a 32 KiB chunk's piece
-                self.dma_q.append("s_add_u32 s96, s96, 0x1000")
-                self.dma_q.append("s_addc_u32 s97, s97, 0")
-                self.dma_q.append("s_add_u32 m0, m0, 0x1000")
-                self.dma_q.append("s_nop 0")
-            line = "global_load_lds_dwordx4 %%[voff], s[96:97] offset:%d" % ((j % 4) * 1024)
-            if self.cfg.get("spread_dma", 1):
-                self.dma_q.append(line)      # issued one per MFMA gap (drain_dma): four in a row hold the wave's issue for ~4 x 16 clocks
-            else:
-                e.emit(line)
+                loads += ["s_add_u32 s96, s96, 0x1000", "s_addc_u32 s97, s97, 0", "s_add_u32 m0, m0, 0x1000", "s_nop 0"]
+            loads.append("global_load_lds_dwordx4 %%[voff], s[96:97] offset:%d" % ((j % 4) * 1024))
+        if self.cfg.get("stagger_dma", 0) and GPC == 4:
+            # The four waves run this stream in lock step, so "one LDS-DMA per MFMA gap" is four waves at the texture path at once.
+            # Staggered: wave w issues its four pieces behind the (4w)th gap after the boundary and skips the other three
+            # places with a scalar branch -- at any moment one wave is issuing.
+            self.dma_n += 1
+            for w in range(NWAVES):
+                lab = ".Ldma_%d_%d_%%=" % (self.dma_n, w)
+                self.dma_q.append(["s_cmp_eq_u32 %%[wave], %d" % w, "s_cbranch_scc0 %s" % lab] + loads + [lab + ":"])
+        elif self.cfg.get("spread_dma", 1):
+            unit = []
+            for ln in loads:                 # (the scalar set-up lines in front of a load go with it)
+                unit.append(ln)
+                if ln.startswith("global_load"):
+                    self.dma_q.append(unit)
+                    unit = []
+        else:
+            for ln in loads:
+                e.emit(ln)
         self.entered = v
 
     def drain_dma(self, n=1):
-        while self.dma_q and n > 0:          # (the scalar set-up lines in front of a load go with it)
-            line = self.dma_q.pop(0)
-            self.e.emit(line)
-            n -= line.startswith("global_load")
+        """issue up to n queued LDS-DMA units (staggered: every `stagger_gap`-th call only)"""
+        if n == 1 and self.cfg.get("stagger_dma", 0):
+            self.dma_tick += 1
+            if self.dma_tick % self.cfg.get("stagger_gap", 4):
+                return
+        while self.dma_q and n > 0:
+            for line in self.dma_q.pop(0):
+                self.e.emit(line)
+            n -= 1
 
     def acquire_for(self, q):
         g = min(q, self.nq - 1)
@@ -462,7 +480,7 @@ def emit_pass(name, table, layers, nq, units, out, cfg=None):
     out.append("// back in v16..v23.  The stream runs the whole ring protocol of one pass (entry, boundaries, walk to the padded end).")
     out.append("constexpr int kMx2PadChunks = %d, kMx2ChunkBytes = %d;" % (padc, CHUNK))
     out.append("template <class Reader>")
-    out.append("__device__ __forceinline__ void mx2_asm_%s(const Reader& rd, lds_cptr bias_lane, lds_cptr rs_lane, half8 (&keep)[2][6], float (&sigma)[2], float (&rgb)[2][3]) {" % name)
+    out.append("__device__ __forceinline__ void mx2_asm_%s(const Reader& rd, int wave, lds_cptr bias_lane, lds_cptr rs_lane, half8 (&keep)[2][6], float (&sigma)[2], float (&rgb)[2][3]) {" % name)
     out.append("    const unsigned src_lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)rd.ring.src[0]), src_hi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)rd.ring.src[0] >> 32));")
     out.append("    const unsigned ldsw = __builtin_amdgcn_readfirstlane((unsigned)(size_t)TGTC_LPTR(rd.ring.lds_wave));")
 
@@ -475,7 +493,7 @@ def emit_pass(name, table, layers, nq, units, out, cfg=None):
     out.append(block_text(lines))
     ins = ['[lane_lo] "v"(rd.ring.lane_lo)', '[lane_hi] "v"(rd.ring.lane_hi)', '[b8_lo] "v"(rd.b8_lo)', '[b8_hi] "v"(rd.b8_hi)',
            '[bias_lane] "v"(bias_lane)', '[rs_lane] "v"(rs_lane)', '[voff] "v"(rd.ring.voff)',
-           '[src_lo] "s"(src_lo)', '[src_hi] "s"(src_hi)', '[ldsw] "s"(ldsw)']
+           '[src_lo] "s"(src_lo)', '[src_hi] "s"(src_hi)', '[ldsw] "s"(ldsw)', '[wave] "s"(wave)']
     clob = ['"memory"', '"scc"', '"m0"', '"s96"', '"s97"']
     pinned = set(range(OUT, OUT + 8)) | set(range(H, H + 48))
     clob += ['"v%d"' % v for v in range(T, LAST_VGPR + 1) if v not in pinned]

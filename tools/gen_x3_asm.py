@@ -102,14 +102,20 @@ class PassX3:
         self.frag_op = {}            # fragment -> id of its last LDS read
         self.op_chunk = {}           # LDS op -> chunk it reads
         self.dma_q = []
+        self.dma_n = self.dma_tick = 0
         self.entered = -1
 
     # ------------------------------------------------------------------------------------------ ring
     def drain_dma(self, n=1):
-        while self.dma_q and n > 0:          # (the scalar set-up lines in front of a load go with it)
-            line = self.dma_q.pop(0)
-            self.e.emit(line)
-            n -= line.startswith("global_load")
+        """issue up to n queued LDS-DMA units (staggered: every `stagger_gap`-th call only)"""
+        if n == 1 and self.cfg.get("stagger_dma", 0):
+            self.dma_tick += 1
+            if self.dma_tick % self.cfg.get("stagger_gap", 4):
+                return
+        while self.dma_q and n > 0:
+            for line in self.dma_q.pop(0):
+                self.e.emit(line)
+            n -= 1
 
     def boundary(self, v):
         e = self.e
@@ -128,10 +134,24 @@ class PassX3:
         e.emit("s_addc_u32 s97, %[src_hi], 0")
         e.emit("s_add_u32 m0, %%[ldsw], 0x%x" % (slot * CHUNK))
         e.emit("s_nop 0")
+        loads = []
         for j in range(GPC):
             if j == 4:                       # the instruction's offset field ends at 4095: second half of a 32 KiB chunk's piece
-                self.dma_q.extend(["s_add_u32 s96, s96, 0x1000", "s_addc_u32 s97, s97, 0", "s_add_u32 m0, m0, 0x1000", "s_nop 0"])
-            self.dma_q.append("global_load_lds_dwordx4 %%[voff], s[96:97] offset:%d" % ((j % 4) * 1024))
+                loads += ["s_add_u32 s96, s96, 0x1000", "s_addc_u32 s97, s97, 0", "s_add_u32 m0, m0, 0x1000", "s_nop 0"]
+            loads.append("global_load_lds_dwordx4 %%[voff], s[96:97] offset:%d" % ((j % 4) * 1024))
+        if self.cfg.get("stagger_dma", 0) and GPC == 4:
+            # (as tools/gen_mx2_asm.py: wave w issues its four pieces at its own place after the boundary, the others branch over it)
+            self.dma_n += 1
+            for w in range(NWAVES):
+                lab = ".Ldmx_%d_%d_%%=" % (self.dma_n, w)
+                self.dma_q.append(["s_cmp_eq_u32 %%[wave], %d" % w, "s_cbranch_scc0 %s" % lab] + loads + [lab + ":"])
+        else:
+            unit = []
+            for ln in loads:
+                unit.append(ln)
+                if ln.startswith("global_load"):
+                    self.dma_q.append(unit)
+                    unit = []
         self.entered = v
 
     def acquire_for(self, f):
@@ -348,7 +368,7 @@ def emit_pass(name, layers, out, cfg=None):
     out.append("// protocol of one pass (entry, boundaries, walk to the padded end).")
     out.append("constexpr int kX3sFrags = %d, kX3sPadChunks = %d, kX3sChunkBytes = %d;" % (gen.nfrag, gen.padc, CHUNK))
     out.append("template <class Ring>")
-    out.append("__device__ __forceinline__ void x3_asm_%s(const Ring& ring, lds_cptr bias_lane, half8 (&keep)[2][4], float (&sigma)[2]) {" % name)
+    out.append("__device__ __forceinline__ void x3_asm_%s(const Ring& ring, int wave, lds_cptr bias_lane, half8 (&keep)[2][4], float (&sigma)[2]) {" % name)
     out.append("    const unsigned src_lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ring.src[0]), src_hi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)ring.src[0] >> 32));")
     out.append("    const unsigned ldsw = __builtin_amdgcn_readfirstlane((unsigned)(size_t)TGTC_LPTR(ring.lds_wave));")
 
@@ -359,7 +379,7 @@ def emit_pass(name, layers, out, cfg=None):
     out.append("    asm volatile(")
     out.append(block_text(lines))
     ins = ['[lane_lo] "v"(ring.lane_lo)', '[lane_hi] "v"(ring.lane_hi)', '[bias_lane] "v"(bias_lane)', '[voff] "v"(ring.voff)',
-           '[src_lo] "s"(src_lo)', '[src_hi] "s"(src_hi)', '[ldsw] "s"(ldsw)']
+           '[src_lo] "s"(src_lo)', '[src_hi] "s"(src_hi)', '[ldsw] "s"(ldsw)', '[wave] "s"(wave)']
     clob = ['"memory"', '"scc"', '"m0"', '"s96"', '"s97"']
     pinned = set(range(OUT, OUT + 2)) | set(range(H, H + 32))
     clob += ['"v%d"' % v for v in range(T, LAST_VGPR + 1) if v not in pinned]
