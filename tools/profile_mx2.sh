@@ -1,14 +1,14 @@
 #!/bin/bash
-# Kernel times and SQ counters of the per-sample fp16mx kernels on the chain path of the headline frame: the two-tile persistent
-# kernel (mlp_nerf_mx2.hip, product) and, with a libtgtc_dev_mx1.so beside it (tools/build_variant.sh mx1 "-DTGTC_MX2=0 -I."
-# mlp_nerf_mx.hip), the one-tile kernel it replaced.  Separate passes for the trace and each counter set (never --pmc with a trace).
+# Kernel times and SQ counters of the per-sample kernels on the split path of the headline frame: the two-tile persistent kernels
+# (mlp_nerf_mx2.hip, mlp_nerf_x3s.hip: product) and, with a libtgtc_dev_mx1.so beside it (tools/build_variant.sh mx1
+# "-DTGTC_MX2=0 -DTGTC_X3S=0 -I." mlp_nerf_mx.hip mlp_nerf.hip), the one-tile kernels they replaced.  Separate passes for the trace and each counter set (never --pmc with a trace).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_mx2; rm -rf $OUT; mkdir -p $OUT; cd $R
 run() {   # tag, extra rocprofv3 args
   rocprofv3 $2 --output-format csv -d $OUT/$1 -- python3 tools/time_fused.py fp16x3+fp16mx > $OUT/$1.log 2> $OUT/$1.err
 }
 for lib in product mx1; do
-  if [ $lib = mx1 ]; then
+  if [ $lib = mx1 ]; then    # (one development build with BOTH one-tile kernels: -DTGTC_MX2=0 on mlp_nerf_mx.hip, -DTGTC_X3S=0 on mlp_nerf.hip)
     [ -f $R/tgtc-style_amd/csrc/libtgtc_dev_mx1.so ] || continue
     export TGTC_LIB=$R/tgtc-style_amd/csrc/libtgtc_dev_mx1.so
   fi
@@ -28,7 +28,7 @@ for lib in ("product", "mx1"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for path in glob.glob(os.path.join(root, lib + "_[abc]/**/*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path, newline="")):
-            if "nerf_mx" in r["Kernel_Name"]:
+            if "nerf_mx" in r["Kernel_Name"] or "nerf_x3s" in r["Kernel_Name"] or "nerf_mlp_kernel" in r["Kernel_Name"]:
                 acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in acc.items():
         print(lib, k)
