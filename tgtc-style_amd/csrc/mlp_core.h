@@ -572,11 +572,23 @@ __device__ __forceinline__ void sincos_turns(double turns, float& s, float& c) {
     }
 }
 
+// elements j0, j0+1 (one 32-bit register) of an encoding's hi / lo B fragments.  SPLIT: the pair's hi halves by one packed
+// convert, the lo halves straight from v_fma_mixlo/mixhi_f16 (v * 1.0 - h in fp32, rounded once: the same bits as
+// (half)(v - (float)h)) -- three instructions per pair instead of the eight the scalar form compiles to; the encoders run
+// once per pass in front of the generated streams, where a lone wave has nobody to hide them (profiles/r4_kernel_variants.md).
 template <bool SPLIT>
 __device__ __forceinline__ void put_pair(half8& hi, half8& lo, int j0, float s, float c) {
-    const half_t hs = (half_t)s, hc = (half_t)c;
-    hi[j0] = hs, hi[j0 + 1] = hc;
-    if constexpr (SPLIT) lo[j0] = (half_t)(s - (float)hs), lo[j0 + 1] = (half_t)(c - (float)hc);
+    if constexpr (SPLIT) {
+        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+        typedef float float2v __attribute__((ext_vector_type(2)));
+        unsigned hpk = __builtin_bit_cast(unsigned, __builtin_convertvector((float2v{s, c}), half2v)), lpk;
+        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lpk) : "v"(s), "v"(hpk));
+        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lpk) : "v"(c), "v"(hpk));
+        set_pair(hi, j0, hpk);
+        set_pair(lo, j0, lpk);
+    } else {
+        hi[j0] = (half_t)s, hi[j0 + 1] = (half_t)c;
+    }
 }
 
 // logical column (0..62) of pair q, function fn (0 sin, 1 cos) in the reference encoding order

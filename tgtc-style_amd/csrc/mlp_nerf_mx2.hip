@@ -65,6 +65,12 @@ __global__ void __launch_bounds__(256, 1) nerf_mx2_kernel(NerfArgs a, long long 
 #if TGTC_MX2_ABL & 1   // timing experiment: no sample loads, no encoding (results wrong by construction)
 #pragma unroll
             for (int c = 0; c < 2; ++c) pe_h[0][c] = pe_h[1][c] = pe_l[0][c] = pe_l[1][c] = de_h[0][c] = de_l[0][c] = half8{(_Float16)(float)(g + n)};
+#elif TGTC_MX2_ABL & 4   // timing experiment: the sample loads (and their wait) without the encoders' arithmetic
+            nerf_load_samples<2, IN_MODE>(a, s_wave, n, pos, dir, sidx);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                pe_h[0][c] = pe_h[1][c] = pe_l[0][c] = pe_l[1][c] = de_h[0][c] = de_l[0][c] =
+                    half8{(_Float16)(float)(pos[c][0] + pos[c][1] + pos[c][2] + dir[c][0] + dir[c][1] + dir[c][2])};
 #else
             nerf_load_samples<2, IN_MODE>(a, s_wave, n, pos, dir, sidx);
             if constexpr (IN_MODE == IN_ENC) nerf_load_encoded<2, true, true>(a, sidx, g, pe_h, pe_l, de_h, de_l);
