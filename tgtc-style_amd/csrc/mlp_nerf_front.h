@@ -84,9 +84,21 @@ __device__ __forceinline__ void nerf_encode(const NerfArgs& a, const double (&po
         half8 h2[2], l2[2];
         encode_point<SPLIT, SPLIT>(pos[c], g, h2, l2, (a.out_pts_enc && live) ? a.out_pts_enc + sidx[c] * 63 : nullptr);
         pe_h[0][c] = h2[0], pe_h[1][c] = h2[1], pe_l[0][c] = l2[0], pe_l[1][c] = l2[1];
-        if constexpr (FULL)
-            encode_dir<SPLIT, SPLIT>(dir[c], g, de_h[0][c], de_l[0][c],
-                                     (a.out_dirs_enc && live) ? a.out_dirs_enc + sidx[c] * 27 : nullptr);
+        if constexpr (FULL) {
+            // consecutive tiles of a wave are samples of the same ray almost always (rays of N = 16 k samples): the direction's
+            // encoding is then the previous tile's, bit for bit, and a lone wave has nobody to hide four more sincos behind
+            bool same = false;
+            if constexpr (NCT > 1) {
+                if (c > 0 && !a.out_dirs_enc)
+                    same = __all(dir[c][0] == dir[c - 1][0] && dir[c][1] == dir[c - 1][1] && dir[c][2] == dir[c - 1][2]);
+            }
+            if (same) {
+                de_h[0][c] = de_h[0][c > 0 ? c - 1 : 0], de_l[0][c] = de_l[0][c > 0 ? c - 1 : 0];
+            } else {
+                encode_dir<SPLIT, SPLIT>(dir[c], g, de_h[0][c], de_l[0][c],
+                                         (a.out_dirs_enc && live) ? a.out_dirs_enc + sidx[c] * 27 : nullptr);
+            }
+        }
     }
 }
 
