@@ -204,6 +204,25 @@ def test_two_tile_fp16mx_kernel_matches_the_one_tile_kernel_bit_for_bit(M):
     assert rel(rgb, rgb2.cpu()) <= 2e-4 and rel(sigma, sigma2.cpu()) <= 2e-4
 
 
+@pytest.mark.parametrize("R,N", [(1, 16), (40, 128), (257, 64), (2200, 128)])
+def test_two_tile_fp16mx_sigma_kernel_matches_the_full_kernel_bit_for_bit(R, N):
+    """fp16mx densities over rays (a coarse pass in fp16mx: `--precision fp16mx`): the sigma-only stream of the two-tile kernel (the
+    first nine layers of the same weight stream) against the densities of the full one, itself pinned to the one-tile kernel above."""
+    from tgtc_style_amd import hip
+    lib = hip.load()
+    rng = np.random.default_rng(R * 1000 + N + 7)
+    ro = torch.from_numpy(rng.uniform(-0.3, 0.3, (R, 3))).cuda()
+    rd = torch.from_numpy(rng.uniform(-1, 1, (R, 3))).cuda()
+    ts = torch.sort(torch.from_numpy(rng.uniform(0, 1, (R, N)).astype(np.float32)).cuda(), -1).values.contiguous()
+    net = make_nerf(0, "coarse", "fp16mx")      # (kept alive: the handle is the module's)
+    h = net.packed().handle
+    s_new = torch.full((R * N,), -7.0, device="cuda")
+    hip.check(lib.tgtc_nerf_forward_rays(h, hip.ptr(ro), hip.ptr(rd), hip.ptr(ts), R, N, None, hip.ptr(s_new), hip.stream()))
+    s_full, rgb = torch.full((R * N,), -7.0, device="cuda"), torch.empty(R * N, 3, device="cuda")
+    hip.check(lib.tgtc_nerf_forward_rays(h, hip.ptr(ro), hip.ptr(rd), hip.ptr(ts), R, N, hip.ptr(rgb), hip.ptr(s_full), hip.stream()))
+    assert torch.equal(s_new, s_full)
+
+
 @pytest.mark.parametrize("R,N", [(1, 16), (3, 128), (40, 128), (700, 128), (257, 64), (2200, 128)])
 def test_two_tile_fp16x3_sigma_kernel_matches_the_one_tile_kernel_bit_for_bit(R, N):
     """tgtc_nerf_forward_rays in fp16x3 with sigma as the only output (the coarse pass of a render) runs the persistent two-tile

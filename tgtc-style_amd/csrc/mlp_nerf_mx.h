@@ -14,8 +14,9 @@ std::vector<LayerSpec> nerf_specs(const tgtc_linear* l);  // mlp_nerf.hip
 int nerf_mx_pack(const tgtc_linear* layers, std::vector<char>& bias, std::vector<char>& stream);
 // launches the kernel for (in_mode, full); no event handling
 int nerf_mx_launch(int in_mode, bool full, const NerfArgs& a, hipStream_t st);
-// the FULL network without the base_remap output: two column tiles per wave, one wave per SIMD, persistent (mlp_nerf_mx2.hip)
-int nerf_mx2_launch(int in_mode, const NerfArgs& a, hipStream_t st);
+// the FULL network without the base_remap output, or densities over rays: two column tiles per wave, one wave per SIMD, persistent
+// (mlp_nerf_mx2.hip)
+int nerf_mx2_launch(int in_mode, bool full, const NerfArgs& a, hipStream_t st);
 // fp16x3, rays in, sigma out (the coarse pass): two column tiles per wave, one wave per SIMD, persistent (mlp_nerf_x3s.hip)
 int nerf_x3s_launch(const NerfArgs& a, hipStream_t st);
 

@@ -214,7 +214,8 @@ int nerf_mx_pack(const tgtc_linear* layers, std::vector<char>& bias_region, std:
 
 int nerf_mx_launch(int in_mode, bool full, const NerfArgs& a, hipStream_t st) {
     using C = CfgMx;
-    if (TGTC_MX2 && full && !a.remap) return nerf_mx2_launch(in_mode, a, st);
+    if (TGTC_MX2 && full && !a.remap) return nerf_mx2_launch(in_mode, true, a, st);
+    if (TGTC_MX2 && !full && in_mode == IN_RAYS && a.sigma && !a.remap && !a.out_pts_enc && !a.out_dirs_enc) return nerf_mx2_launch(in_mode, false, a, st);
     const unsigned nwg = (unsigned)((a.M + C::SAMPLES_PER_WG - 1) / C::SAMPLES_PER_WG);
     const dim3 block(C::NWAVES * 64);
     switch (in_mode * 2 + (full ? 1 : 0)) {

@@ -1,4 +1,4 @@
-// The FULL NeRF MLP in TGTC_PREC_FP16_FP6 on TWO column tiles per wave, one wave per SIMD: a persistent kernel (one
+// The NeRF MLP (all twelve layers, or the trunk + sigma head of a coarse pass) in TGTC_PREC_FP16_FP6 on TWO column tiles per wave, one wave per SIMD: a persistent kernel (one
 // workgroup of four waves per CU, 128 samples per pass, the weight ring never drains between passes) whose pass is ONE
 // generated instruction stream (tools/gen_mx2_asm.py -> mx2_asm_nerf.inc).  Same arithmetic per sample, in the same order,
 // as nerf_mx_kernel (mlp_nerf_mx.hip, reference models.py:63-117 inside :182-223): bit-identical outputs, half the LDS
@@ -22,15 +22,17 @@ using CfgMx2 = MlpCfg<4, 2, false, 4>;
 #define TGTC_MX2_ABL 0
 #endif
 
-template <int IN_MODE>
+// FULL = false: the trunk + sigma head alone (the coarse pass of a render whose coarse network is fp16mx), rays in, densities out
+template <int IN_MODE, bool FULL>
 __global__ void __launch_bounds__(256, 1) nerf_mx2_kernel(NerfArgs a, long long n_pass) {
     using C = CfgMx2;
-    constexpr int NUNITS = nerf_mx_units(true);
+    constexpr int NUNITS = nerf_mx_units(FULL);
     using Reader = MxReader<C, SingleStreamMap<NUNITS>, kNerfMxTable, true>;
     // the stream's ring: 128 KiB in chunks of kMx2ChunkBytes (the generator's `chunk`), every wave moves 1/4 of a chunk
     constexpr int kChunk = kMx2ChunkBytes, kSlots = C::RING_BYTES / kChunk, kLook = kSlots - 1, kPiece = kChunk / C::NWAVES;
     constexpr int kPad = ((NUNITS * 1024 + kChunk - 1) / kChunk + kSlots - 1) / kSlots * kSlots;
-    static_assert(kPad == kMx2PadChunks && C::RING_BYTES == 131072 && kPiece % 4096 == 0, "the generated stream was laid out for this ring");
+    static_assert(kPad == (FULL ? kMx2PadChunks : kMx2SigmaPadChunks) && C::RING_BYTES == 131072 && kPiece % 4096 == 0,
+                  "the generated stream was laid out for this ring");
 
     // ring | biases + row exponents
     __shared__ __attribute__((aligned(16))) char smem[C::RING_BYTES + kNerfBiasBytes];
@@ -55,7 +57,7 @@ __global__ void __launch_bounds__(256, 1) nerf_mx2_kernel(NerfArgs a, long long 
 
     for (long long p = blockIdx.x; p < n_pass; p += gridDim.x) {
         const long long s_wave = p * C::SAMPLES_PER_WG + wave * C::SAMPLES_PER_WAVE;
-        half8 keep[2][6];
+        half8 keep[2][FULL ? 6 : 4];
         {
             const int lane = fresh_lane_id();
             const int g = lane >> 4, n = lane & 15;
@@ -73,13 +75,14 @@ __global__ void __launch_bounds__(256, 1) nerf_mx2_kernel(NerfArgs a, long long 
                     half8{(_Float16)(float)(pos[c][0] + pos[c][1] + pos[c][2] + dir[c][0] + dir[c][1] + dir[c][2])};
 #else
             nerf_load_samples<2, IN_MODE>(a, s_wave, n, pos, dir, sidx);
-            if constexpr (IN_MODE == IN_ENC) nerf_load_encoded<2, true, true>(a, sidx, g, pe_h, pe_l, de_h, de_l);
-            else nerf_encode<2, true, true>(a, pos, dir, sidx, g, pe_h, pe_l, de_h, de_l);
+            if constexpr (IN_MODE == IN_ENC) nerf_load_encoded<2, true, FULL>(a, sidx, g, pe_h, pe_l, de_h, de_l);
+            else nerf_encode<2, true, FULL>(a, pos, dir, sidx, g, pe_h, pe_l, de_h, de_l);
 #endif
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
-                keep[c][0] = pe_h[0][c], keep[c][1] = pe_h[1][c], keep[c][2] = pe_l[0][c], keep[c][3] = pe_l[1][c], keep[c][4] = de_h[0][c],
-                keep[c][5] = de_l[0][c];
+            for (int c = 0; c < 2; ++c) {
+                keep[c][0] = pe_h[0][c], keep[c][1] = pe_h[1][c], keep[c][2] = pe_l[0][c], keep[c][3] = pe_l[1][c];
+                if constexpr (FULL) keep[c][4] = de_h[0][c], keep[c][5] = de_l[0][c];
+            }
         }
         // per-lane addresses from a lane id read HERE: nothing but them and the loop's scalars lives across the stream
         rd.relane(smem, wave);
@@ -87,8 +90,9 @@ __global__ void __launch_bounds__(256, 1) nerf_mx2_kernel(NerfArgs a, long long 
         rd.ring.voff = wave * kPiece + fl * 16;
         const lds_cptr bias_lane = opaque((lds_cptr)smem + C::RING_BYTES + 16 * (fl >> 4));
         const lds_cptr rs_lane = opaque((lds_cptr)smem + C::RING_BYTES + kNerfMxScaleOff + 2 * (fl & 15));
-        float sigma[2], rgb[2][3];
-        mx2_asm_nerf_full_pass(rd, wave, bias_lane, rs_lane, keep, sigma, rgb);
+        float sigma[2], rgb[2][3] = {};
+        if constexpr (FULL) mx2_asm_nerf_full_pass(rd, wave, bias_lane, rs_lane, keep, sigma, rgb);
+        else mx2_asm_nerf_sigma_pass(rd, wave, bias_lane, rs_lane, keep, sigma);
         const int lane = fresh_lane_id();
         if (lane < 16 && !(TGTC_MX2_ABL & 2)) {   // (2: timing experiment without the output stores)
 #pragma unroll
@@ -96,9 +100,11 @@ __global__ void __launch_bounds__(256, 1) nerf_mx2_kernel(NerfArgs a, long long 
                 const long long s = s_wave + c * 16 + lane;
                 if (s < a.M) {
                     if (a.sigma) a.sigma[s] = sigma[c];
-                    if (a.rgb) {
+                    if constexpr (FULL) {
+                        if (a.rgb) {
 #pragma unroll
-                        for (int r = 0; r < 3; ++r) a.rgb[s * 3 + r] = 1.0f / (1.0f + expf(-rgb[c][r]));   // models.py:111
+                            for (int r = 0; r < 3; ++r) a.rgb[s * 3 + r] = 1.0f / (1.0f + expf(-rgb[c][r]));   // models.py:111
+                        }
                     }
                 }
             }
@@ -107,7 +113,7 @@ __global__ void __launch_bounds__(256, 1) nerf_mx2_kernel(NerfArgs a, long long 
     wait_vmcnt<0>();   // the look-ahead of a pass that will not run: its LDS-DMA must have landed before the workgroup ends
 }
 
-int nerf_mx2_launch(int in_mode, const NerfArgs& a, hipStream_t st) {
+int nerf_mx2_launch(int in_mode, bool full, const NerfArgs& a, hipStream_t st) {
     using C = CfgMx2;
     static int cus = 0;
     if (cus == 0) {
@@ -119,11 +125,12 @@ int nerf_mx2_launch(int in_mode, const NerfArgs& a, hipStream_t st) {
     const long long n_pass = (a.M + C::SAMPLES_PER_WG - 1) / C::SAMPLES_PER_WG;
     const unsigned nwg = (unsigned)(n_pass < cus ? n_pass : cus);
     const dim3 block(C::NWAVES * 64);
-    switch (in_mode) {
-        case IN_RAYS: nerf_mx2_kernel<IN_RAYS><<<nwg, block, 0, st>>>(a, n_pass); break;
-        case IN_PTS: nerf_mx2_kernel<IN_PTS><<<nwg, block, 0, st>>>(a, n_pass); break;
-        case IN_ENC: nerf_mx2_kernel<IN_ENC><<<nwg, block, 0, st>>>(a, n_pass); break;
-        default: return fail(TGTC_ERR_UNSUPPORTED, "nerf (fp16+fp6, two tiles): no kernel for input mode %d", in_mode);
+    switch (in_mode * 2 + (full ? 1 : 0)) {
+        case IN_RAYS * 2 + 0: nerf_mx2_kernel<IN_RAYS, false><<<nwg, block, 0, st>>>(a, n_pass); break;
+        case IN_RAYS * 2 + 1: nerf_mx2_kernel<IN_RAYS, true><<<nwg, block, 0, st>>>(a, n_pass); break;
+        case IN_PTS * 2 + 1: nerf_mx2_kernel<IN_PTS, true><<<nwg, block, 0, st>>>(a, n_pass); break;
+        case IN_ENC * 2 + 1: nerf_mx2_kernel<IN_ENC, true><<<nwg, block, 0, st>>>(a, n_pass); break;
+        default: return fail(TGTC_ERR_UNSUPPORTED, "nerf (fp16+fp6, two tiles): no kernel for input mode %d, full %d", in_mode, (int)full);
     }
     TGTC_LAUNCH_CHECK();
     return TGTC_OK;

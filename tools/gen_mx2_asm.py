@@ -96,8 +96,9 @@ def nerf_full_layers():
 
 
 class Pass2:
-    def __init__(self, table, layers, nq, padc, cfg=None):
+    def __init__(self, table, layers, nq, padc, cfg=None, nkeep=24):
         self.t, self.layers, self.nq, self.padc = table, layers, nq, padc
+        self.nkeep = nkeep           # encoding registers per tile handed over: 24 (point + direction) or 16 (sigma-only pass)
         self.cfg = cfg or {}         # timing experiments (results wrong by construction): abl_epi, abl_reads, abl_ring, abl_barrier, abl_dma, abl_cvt
         self.e = Emitter()
         self.unit_op, self.unit_chunk = {}, {}
@@ -376,7 +377,7 @@ class Pass2:
 
         # ---- prologue: the encodings to their AGPRs, enter the pass, biases of three row tiles, groups 0 and 1
         for ct in range(NCT):
-            for i in range(24):
+            for i in range(self.nkeep):
                 e.emit("v_accvgpr_write_b32 %s, %s" % (A(AKEEP + 24 * ct + i), V(H + 24 * ct + i)))
         self.boundary(0)
         for r in range(3):
@@ -464,10 +465,11 @@ def block_text(lines):
     return "\n".join('        "%s\\n\\t"' % ln for ln in lines)
 
 
-def emit_pass(name, table, layers, nq, units, out, cfg=None):
+def emit_pass(name, table, layers, nq, units, out, cfg=None, full=True):
     nchunk = (units * 1024 + CHUNK - 1) // CHUNK
     padc = (nchunk + SLOTS - 1) // SLOTS * SLOTS
-    gen = Pass2(table, layers, nq, padc, cfg)
+    nfrag = 6 if full else 4                     # keep fragments per tile: Ph0 Ph1 Pl0 Pl1 [Dh Dl]
+    gen = Pass2(table, layers, nq, padc, cfg, nkeep=4 * nfrag)
     lines = gen.generate()
     stats = {}
     for ln in lines:
@@ -475,28 +477,36 @@ def emit_pass(name, table, layers, nq, units, out, cfg=None):
         stats[k] = stats.get(k, 0) + 1
     out.append("// pass %s: %d groups, %d layers, %d chunks (padded %d); %d instructions; %s" % (
         name, nq, len(layers), nchunk, padc, len(lines), ", ".join("%s %d" % kv for kv in sorted(stats.items(), key=lambda kv: -kv[1])[:14])))
-    out.append("// keep[ct][0..5] = Ph[0], Ph[1], Pl[0], Pl[1], Dh, Dl of column tile ct (fp16 hi / lo B fragments of the encodings), handed over in")
-    out.append("// v122..v169 and moved to a152..a199 by the stream; sigma[ct] (lanes 0..15) and rows 0..2 of the colour head's accumulator come")
-    out.append("// back in v16..v23.  The stream runs the whole ring protocol of one pass (entry, boundaries, walk to the padded end).")
-    out.append("constexpr int kMx2PadChunks = %d, kMx2ChunkBytes = %d;" % (padc, CHUNK))
+    if full:
+        out.append("// keep[ct][0..5] = Ph[0], Ph[1], Pl[0], Pl[1], Dh, Dl of column tile ct (fp16 hi / lo B fragments of the encodings), handed over in")
+        out.append("// v122..v169 and moved to a152..a199 by the stream; sigma[ct] (lanes 0..15) and rows 0..2 of the colour head's accumulator come")
+        out.append("// back in v16..v23.  The stream runs the whole ring protocol of one pass (entry, boundaries, walk to the padded end).")
+        out.append("constexpr int kMx2PadChunks = %d, kMx2ChunkBytes = %d;" % (padc, CHUNK))
+    else:
+        out.append("// the trunk + sigma head alone (the first nine layers of the same stream): keep[ct][0..3] = Ph[0], Ph[1], Pl[0], Pl[1]; sigma[ct] in v16, v17")
+        out.append("constexpr int kMx2SigmaPadChunks = %d;" % padc)
     out.append("template <class Reader>")
-    out.append("__device__ __forceinline__ void mx2_asm_%s(const Reader& rd, int wave, lds_cptr bias_lane, lds_cptr rs_lane, half8 (&keep)[2][6], float (&sigma)[2], float (&rgb)[2][3]) {" % name)
+    tail = ", float (&rgb)[2][3]" if full else ""
+    out.append("__device__ __forceinline__ void mx2_asm_%s(const Reader& rd, int wave, lds_cptr bias_lane, lds_cptr rs_lane, half8 (&keep)[2][%d], float (&sigma)[2]%s) {" % (name, nfrag, tail))
     out.append("    const unsigned src_lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)rd.ring.src[0]), src_hi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)rd.ring.src[0] >> 32));")
     out.append("    const unsigned ldsw = __builtin_amdgcn_readfirstlane((unsigned)(size_t)TGTC_LPTR(rd.ring.lds_wave));")
 
     def rg(base, n):
         return "{v[%d:%d]}" % (base, base + n - 1)
     outs = ['"=&{v%d}"(sigma[%d])' % (OUT + ct, ct) for ct in range(NCT)]
-    outs += ['"=&{v%d}"(rgb[%d][%d])' % (OUT + 2 + 3 * ct + i, ct, i) for ct in range(NCT) for i in range(3)]
-    outs += ['"+%s"(keep[%d][%d])' % (rg(H + 24 * ct + 4 * i, 4), ct, i) for ct in range(NCT) for i in range(6)]
+    if full:
+        outs += ['"=&{v%d}"(rgb[%d][%d])' % (OUT + 2 + 3 * ct + i, ct, i) for ct in range(NCT) for i in range(3)]
+    outs += ['"+%s"(keep[%d][%d])' % (rg(H + 24 * ct + 4 * i, 4), ct, i) for ct in range(NCT) for i in range(nfrag)]
     out.append("    asm volatile(")
     out.append(block_text(lines))
     ins = ['[lane_lo] "v"(rd.ring.lane_lo)', '[lane_hi] "v"(rd.ring.lane_hi)', '[b8_lo] "v"(rd.b8_lo)', '[b8_hi] "v"(rd.b8_hi)',
            '[bias_lane] "v"(bias_lane)', '[rs_lane] "v"(rs_lane)', '[voff] "v"(rd.ring.voff)',
            '[src_lo] "s"(src_lo)', '[src_hi] "s"(src_hi)', '[ldsw] "s"(ldsw)', '[wave] "s"(wave)']
     clob = ['"memory"', '"scc"', '"m0"', '"s96"', '"s97"']
-    pinned = set(range(OUT, OUT + 8)) | set(range(H, H + 48))
-    clob += ['"v%d"' % v for v in range(T, LAST_VGPR + 1) if v not in pinned]
+    pinned = set(range(OUT, OUT + (8 if full else 2)))
+    for ct in range(NCT):
+        pinned |= set(range(H + 24 * ct, H + 24 * ct + 4 * nfrag))
+    clob += ['"v%d"' % v for v in range(OUT, LAST_VGPR + 1) if v not in pinned]
     clob += ['"a%d"' % a for a in range(N_AGPR)]
     out.append("        : " + ", ".join(outs))
     out.append("        : " + ", ".join(ins))
@@ -526,6 +536,8 @@ def main():
     nq = t.first[12]
     units = t.bytes_upto(nq) // 1024
     emit_pass("nerf_full_pass", t, nerf_full_layers(), nq, units, out, cfg)
+    nq_s = t.first[9]
+    emit_pass("nerf_sigma_pass", t, nerf_full_layers()[:9], nq_s, t.bytes_upto(nq_s) // 1024, out, cfg, full=False)
     print("\n".join(out))
 
 
