@@ -458,6 +458,19 @@ def run_headline(args, precision, rank, world, dist):
                                                                    hip.ptr(rgb_s), hip.ptr(sig_s), hip.stream()))
         _, kernel_ms, _ = time_loop(fine_pass, max(args.steps, 3), 1)
         flop_launch = 2.0 * MAC_FULL * rays_launch * n_all
+        # the frame's second kernel, timed the same way: the coarse pass (fp16x3, densities only) on its two-tile kernel
+        ts_c = torch.linspace(0., 1., N_COARSE, device="cuda").expand(rays_launch, N_COARSE).contiguous()
+        sig_c = torch.empty(rays_launch * N_COARSE, device="cuda")
+        h_c = renderer.coarse.packed().handle
+        coarse_pass = lambda i: hip.check(lib.tgtc_nerf_forward_rays(h_c, hip.ptr(o), hip.ptr(d), hip.ptr(ts_c), rays_launch, N_COARSE,
+                                                                     None, hip.ptr(sig_c), hip.stream()))
+        _, coarse_ms, _ = time_loop(coarse_pass, max(args.steps, 3), 1)
+        coarse_flop = 2.0 * MAC_SIGMA * rays_launch * N_COARSE
+        whole["kernels"] = {
+            "nerf_mx2_kernel (fine pass, fp16mx)": {"ms": kernel_ms, "frac": flop_launch / (kernel_ms * 1e-3) / 1e12 / PEAK_FP16_TFLOPS,
+                                                    "mfma_pipe_frac": flop_launch * MFMA_PER_PRODUCT["fp16mx"] / (kernel_ms * 1e-3) / 1e12 / PEAK_FP16_TFLOPS},
+            "nerf_x3s_kernel (coarse pass, fp16x3, densities)": {"ms": coarse_ms, "frac": coarse_flop / (coarse_ms * 1e-3) / 1e12 / PEAK_FP16_TFLOPS,
+                                                                 "mfma_pipe_frac": coarse_flop * MFMA_PER_PRODUCT["fp16x3"] / (coarse_ms * 1e-3) / 1e12 / PEAK_FP16_TFLOPS}}
         kname = ("nerf_mx2_kernel (the fine pass of %d rays in one launch: PE + full NeRF MLP on %d depths per ray; the frame's other "
                  "launches: ray generation, coarse depths, coarse MLP (fp16x3, sigma only), two composites, fine sampling -- "
                  "`whole_render` is all of them)" % (rays_launch, n_all))
