@@ -298,7 +298,11 @@ class PassX3:
                 is_act = ks < L.act
                 if is_act and tail_of[0] == (L.src, ks):
                     flush(gap)
+                # one counted wait per PAIR of fragments: with eight fragments read ahead the next one landed long ago, and a wait
+                # is an instruction the lone wave has to issue like any other (wait_pairs=0: one per fragment, 0.19 per MFMA)
                 ops_needed = [self.frag_op[fr]] if self.frag_op.get(fr) is not None else []
+                if self.cfg.get("wait_pairs", 1) and fr % 2 == 0 and self.frag_op.get(fr + 1) is not None:
+                    ops_needed.append(self.frag_op[fr + 1])
                 if ks == 0:
                     ops_needed.append(bias_op[grt])
                 if ops_needed:
